@@ -1,0 +1,565 @@
+// NHWC im2col-free convolution as an implicit GEMM on the CDNA4 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
+//
+//   out[p, n] = post2 + post + mul * act( bias[n] + pre + sum_{ty,tx,c} in[pix(p)+(ty,tx), c] * W[ty,tx,c,n] )
+//
+// * M = output positions p=(b,oy,ox), N = output channels, K = taps x concatenated input
+//   channels.  The input is a virtual channel-concat of up to 4 NHWC "segments"
+//   (pointer + channel count + pixel stride), so torch.cat of the reference
+//   (models/pic.py:528-529,548,598-599,635) never materialises.
+// * Each K chunk (one tap, BK consecutive channels) of the A tile is BM rows of BK
+//   contiguous floats in HBM/L2 -> coalesced 16-byte loads, zero-filled at the halo,
+//   staged through LDS (row stride BK+4 floats: conflict-free ds_read_b128).
+// * Weights are pre-packed [tap][k-chunk][n][BK] so the B tile is one contiguous block.
+// * Double-buffered LDS, next chunk prefetched into registers under the MFMAs,
+//   one barrier per chunk.
+// * Grouped launch: up to 8 independent problems share one grid.
+//
+// Replaces nn.Conv2d / nn.ConvTranspose2d (per sub-pixel phase) / nn.Linear plus the
+// surrounding element-wise ops of reference layers/layers.py:5-86, layers/gdn.py:62-75,
+// layers/rem.py:52-66,130-141, models/pic.py:528-551,598-641.
+#include "common.h"
+
+namespace vam {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvP {
+  const float* seg_ptr[VAM_MAX_SEG];
+  int seg_ld[VAM_MAX_SEG];
+  int seg_end[VAM_MAX_SEG];  // cumulative channel end of each segment
+  int n_seg;
+  int H, W, HW;
+  int kh, kw, stride, pad_y, pad_x;
+  int Ho, Wo, HoWo;
+  int P;        // B*Ho*Wo
+  int N, Npad;  // output channels, padded to 32
+  int Cin, Kc;  // total input channels, k-chunks per tap
+  const float* wpack;
+  const float* bias;
+  float* out;
+  int ldo, Hf, Wf, osy, osx, ooy, oox, Cq, act, flags;
+  const float* pre;
+  const float* mul;
+  const float* post;
+  const float* post2;
+  int ld_pre, ld_mul, ld_post, ld_post2;
+  int tiles_n;
+};
+
+struct GroupArgs {
+  int nprob;
+  int tile_start[VAM_MAX_GROUP + 1];
+  ConvP p[VAM_MAX_GROUP];
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case VAM_ACT_GELU: return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));
+    case VAM_ACT_LEAKY: return v > 0.f ? v : v * 0.01f;
+    case VAM_ACT_HALF_TANH: return 0.5f * tanhf(v);
+    case VAM_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case VAM_ACT_CLAMP01: return fminf(fmaxf(v, 0.f), 1.f);
+    case VAM_ACT_RSQRT: return 1.0f / sqrtf(v);
+    case VAM_ACT_SQRT: return sqrtf(v);
+    default: return v;
+  }
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupArgs args) {
+  constexpr int NT = WGM * WGN * 64;         // threads per block
+  constexpr int LDS_LD = BK + 4;             // floats per LDS row
+  constexpr int TM = BM / WGM / 32;          // 32x32 tiles per wave along M
+  constexpr int TN = BN / WGN / 32;
+  constexpr int CPR = BK / 4;                // float4 chunks per row
+  constexpr int RPP = NT / CPR;              // rows covered per pass of the block
+  constexpr int NA = (BM + RPP - 1) / RPP;   // A float4 per thread
+  constexpr int NB = (BN + RPP - 1) / RPP;
+  constexpr bool A_FULL = (BM % RPP) == 0, B_FULL = (BN % RPP) == 0;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                          // [2][BM][LDS_LD]
+  float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+
+  // ---- which problem / tile
+  int bid = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < VAM_MAX_GROUP; ++i)
+    if (i < args.nprob && bid >= args.tile_start[i]) pi = i;
+  const ConvP& P = args.p[pi];
+  const int t = bid - args.tile_start[pi];
+  const int tn = t % P.tiles_n, tm = t / P.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int ld_row = tid / CPR;              // row within a pass
+  const int ld_col = (tid % CPR) * 4;        // float offset within the chunk
+
+  // ---- per-thread A rows: decode output position once
+  int a_iy0[NA], a_ix0[NA], a_boff[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int p = m0 + ld_row + i * RPP;
+    if (p < P.P && (A_FULL || ld_row + i * RPP < BM)) {
+      int b = p / P.HoWo;
+      int r = p - b * P.HoWo;
+      int oy = r / P.Wo;
+      int ox = r - oy * P.Wo;
+      a_iy0[i] = oy * P.stride - P.pad_y;
+      a_ix0[i] = ox * P.stride - P.pad_x;
+      a_boff[i] = b * P.HW;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = 0;
+      a_boff[i] = 0;
+    }
+  }
+  const bool sq = (P.flags & VAM_CONV_SQUARE_IN) != 0;
+
+  float4 ra[NA], rb[NB];
+  const int n_taps = P.kh * P.kw;
+  const int n_chunks = n_taps * P.Kc;
+
+  // chunk state (block-uniform)
+  int c_ty = 0, c_tx = 0, c_kc = 0, c_seg = 0;
+
+  auto gload = [&](int chunk) {
+    const int cc0 = c_kc * BK;
+    while (cc0 >= P.seg_end[c_seg]) ++c_seg;
+    const int seg_begin = c_seg ? P.seg_end[c_seg - 1] : 0;
+    const float* sp = P.seg_ptr[c_seg];
+    const int sld = P.seg_ld[c_seg];
+    const int coff = cc0 - seg_begin + ld_col;
+    const bool cok = (cc0 + ld_col) < P.Cin;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int iy = a_iy0[i] + c_ty, ix = a_ix0[i] + c_tx;
+      bool ok = cok && ((unsigned)iy < (unsigned)P.H) && ((unsigned)ix < (unsigned)P.W);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* src = sp + (size_t)(a_boff[i] + iy * P.W + ix) * sld + coff;
+        v = *reinterpret_cast<const float4*>(src);
+        if (sq) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
+      }
+      ra[i] = v;
+    }
+    const float* wsrc = P.wpack + ((size_t)chunk * P.Npad + n0) * BK + ld_col;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int r = ld_row + i * RPP;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((B_FULL || r < BN) && n0 + r < P.Npad) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * BK);
+      rb[i] = v;
+    }
+    // advance chunk state
+    if (++c_kc == P.Kc) {
+      c_kc = 0;
+      c_seg = 0;
+      if (++c_tx == P.kw) { c_tx = 0; ++c_ty; }
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* a = sA + buf * BM * LDS_LD;
+    float* b = sB + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (A_FULL || ld_row + i * RPP < BM)
+        *reinterpret_cast<float4*>(a + (ld_row + i * RPP) * LDS_LD + ld_col) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (B_FULL || ld_row + i * RPP < BN)
+        *reinterpret_cast<float4*>(b + (ld_row + i * RPP) * LDS_LD + ld_col) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_row0 = (wm * TM * 32 + l31) * LDS_LD + lh * 4;
+  const int b_row0 = (wn * TN * 32 + l31) * LDS_LD + lh * 4;
+
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < n_chunks) gload(ch + 1);
+    const float* a = sA + buf * BM * LDS_LD + a_row0;
+    const float* b = sB + buf * BN * LDS_LD + b_row0;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (ch + 1 < n_chunks) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  Stage the block's C tile through LDS (C layout of the 32x32 MFMA:
+  // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then stream it out with one
+  // float4 of 4 consecutive channels per lane: 16-byte aux loads and stores, and the
+  // activation code exists once instead of once per accumulator register.
+  constexpr int LDC = BN + 4;
+  float* sC = smem;  // the pipeline buffers are dead after the last barrier of the loop
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sC[row * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const bool ps2 = (P.flags & VAM_CONV_PS2) != 0;
+  const bool nchw = (P.flags & VAM_CONV_OUT_NCHW) != 0;
+  const bool dense = !ps2 && !nchw && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
+                     P.Hf == P.Ho && P.Wf == P.Wo;
+  const bool vec_ok = !nchw && (!ps2 || (P.Cq & 3) == 0);
+  const int Cc = ps2 ? P.Cq : P.N;
+  const size_t HfWf = (size_t)P.Hf * P.Wf;
+  for (int it = tid; it < BM * (BN / 4); it += NT) {
+    const int row = it / (BN / 4);
+    const int c4 = (it - row * (BN / 4)) * 4;
+    const int p = m0 + row;
+    const int n = n0 + c4;
+    if (p >= P.P || n >= P.N) continue;
+    const float4 av = *reinterpret_cast<const float4*>(sC + row * LDC + c4);
+    float v[4] = {av.x, av.y, av.z, av.w};
+    int ob = 0, oy = 0, ox = 0;
+    if (!dense) {
+      ob = p / P.HoWo;
+      int rr = p - ob * P.HoWo;
+      oy = rr / P.Wo;
+      ox = rr - oy * P.Wo;
+    }
+    if (vec_ok) {
+      int cch = n;
+      size_t opix;
+      if (dense) {
+        opix = (size_t)p;
+      } else if (ps2) {
+        int ph = n / P.Cq;
+        cch = n - ph * P.Cq;
+        opix = ((size_t)ob * P.Hf + 2 * oy + (ph >> 1)) * P.Wf + 2 * ox + (ph & 1);
+      } else {
+        opix = ((size_t)ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
+      }
+      if (P.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (P.pre) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
+      if (P.mul) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
+        v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
+      }
+      if (P.post) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+      if (P.post2) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+      *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
+      for (int k = 0; k < 4; ++k) {
+        const int nn = n + k;
+        if (nn >= P.N) break;
+        int cch = nn, oyf, oxf;
+        if (ps2) {
+          int ph = nn / P.Cq;
+          cch = nn - ph * P.Cq;
+          oyf = 2 * oy + (ph >> 1);
+          oxf = 2 * ox + (ph & 1);
+        } else {
+          oyf = oy * P.osy + P.ooy;
+          oxf = ox * P.osx + P.oox;
+        }
+        const size_t opix = ((size_t)ob * P.Hf + oyf) * P.Wf + oxf;
+        float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
+        if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
+        x = apply_act(x, P.act);
+        if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
+        if (P.post) x = x + P.post[opix * P.ld_post + cch];
+        if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
+        if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (size_t)oyf * P.Wf + oxf] = x;
+        else P.out[opix * P.ldo + cch] = x;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight packing
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode,
+                                    int phase, int kh, int kw, int cin, int n, int npad, int bk, int kc,
+                                    long total) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  int kk = (int)(d % bk);
+  long r = d / bk;
+  int nn = (int)(r % npad);
+  r /= npad;
+  int c_chunk = (int)(r % kc);
+  int tap = (int)(r / kc);
+  int ty = tap / kw, tx = tap % kw;
+  int cc = c_chunk * bk + kk;
+  float v = 0.f;
+  if (nn < n && cc < cin) {
+    if (mode == VAM_PACK_CONV) {
+      v = src[(((size_t)nn * cin + cc) * kh + ty) * kw + tx];
+    } else if (mode == VAM_PACK_PS2) {
+      int cq = n / 4;
+      int ph = nn / cq, c = nn - ph * cq;
+      v = src[(((size_t)(c * 4 + ph) * cin + cc) * kh + ty) * kw + tx];
+    } else if (mode == VAM_PACK_GDN) {
+      float g = src[(size_t)nn * cin + cc];
+      const float bound = 3.814697265625e-06f;       // 2^-18 = sqrt(0 + 2^-36)
+      const float ped = 1.4551915228366852e-11f;     // 2^-36
+      g = fmaxf(g, bound);
+      v = g * g - ped;
+    } else if (mode == VAM_PACK_DECONV5S2) {
+      if (phase >= 0) {
+        int py = phase >> 1, px = phase & 1;
+        int dy = ty - (py ? 0 : 1), dx = tx - (px ? 0 : 1);
+        int ky = py + 2 - 2 * dy, kx = px + 2 - 2 * dx;
+        if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5)
+          v = src[(((size_t)cc * n + nn) * 5 + ky) * 5 + kx];
+      } else {
+        int cout = n / 4;
+        int ph = nn / cout, c = nn - ph * cout;
+        int py = ph >> 1, px = ph & 1;
+        int dy = ty - 1, dx = tx - 1;
+        int ky = py + 2 - 2 * dy, kx = px + 2 - 2 * dx;
+        if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5)
+          v = src[(((size_t)cc * cout + c) * 5 + ky) * 5 + kx];
+      }
+    }
+  }
+  dst[d] = v;
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v;
+  if (mode == VAM_PACK_PS2) {
+    int cq = n / 4;
+    int ph = i / cq, c = i - ph * cq;
+    v = src[c * 4 + ph];
+  } else if (mode == VAM_PACK_DECONV5S2) {
+    int cout = n / 4;
+    v = src[i % cout];
+  } else if (mode == VAM_PACK_GDN) {
+    // beta: NonNegativeParametrizer(minimum=1e-6): bound = sqrt(1e-6 + 2^-36) rounded to fp32
+    const float bound = (float)1.0000072759311445e-03;
+    const float ped = 1.4551915228366852e-11f;
+    float b = fmaxf(src[i], bound);
+    v = b * b - ped;
+  } else {
+    v = src[i];
+  }
+  dst[i] = v;
+}
+
+static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
+  constexpr size_t pipe = 2 * (BM + BN) * (BK + 4) * sizeof(float);
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t smem = pipe > ctile ? pipe : ctile;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN>), dim3(total_tiles), dim3(WGM * WGN * 64), smem, s, ga);
+  return check_launch("conv_igemm_kernel");
+}
+
+}  // namespace vam
+
+using namespace vam;
+
+extern "C" {
+
+size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
+  int bk = bk_for(cin);
+  int kc = (cin + bk - 1) / bk;
+  int npad = (n + 31) / 32 * 32;
+  return (size_t)kh * kw * kc * npad * bk;
+}
+
+int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int kh, int kw, int cin, int n,
+                          void* stream) {
+  VAM_REQUIRE(src && dst && kh > 0 && kw > 0 && cin > 0 && n > 0, "vam_pack_conv_weights: bad arguments");
+  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_GDN, "vam_pack_conv_weights: bad mode %d", mode);
+  if (mode == VAM_PACK_PS2) VAM_REQUIRE(n % 4 == 0, "PS2 pack needs N %% 4 == 0");
+  if (mode == VAM_PACK_DECONV5S2 && phase < 0) VAM_REQUIRE(n % 4 == 0 && kh == 3 && kw == 3, "merged deconv pack needs 3x3, N=4*Cout");
+  if (mode == VAM_PACK_DECONV5S2 && phase >= 0)
+    VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
+  if (mode == VAM_PACK_GDN) VAM_REQUIRE(kh == 1 && kw == 1, "GDN pack is 1x1");
+  int bk = bk_for(cin);
+  int kc = (cin + bk - 1) / bk;
+  int npad = (n + 31) / 32 * 32;
+  long total = (long)kh * kw * kc * npad * bk;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, mode,
+                     phase, kh, kw, cin, n, npad, bk, kc, total);
+  return check_launch("pack_weights_kernel");
+}
+
+int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream) {
+  VAM_REQUIRE(src && dst && n > 0, "vam_pack_bias: bad arguments");
+  hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, mode, n);
+  return check_launch("pack_bias_kernel");
+}
+
+int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
+  VAM_REQUIRE(probs && nprob >= 1 && nprob <= VAM_MAX_GROUP, "vam_conv_group: 1..%d problems", VAM_MAX_GROUP);
+  GroupArgs ga;
+  ga.nprob = nprob;
+  int bk = 0;
+  long max_p = 0;
+  int max_n = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const vam_conv& c = probs[i];
+    ConvP& p = ga.p[i];
+    VAM_REQUIRE(c.n_seg >= 1 && c.n_seg <= VAM_MAX_SEG, "conv[%d]: n_seg %d", i, c.n_seg);
+    VAM_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.Ho > 0 && c.Wo > 0 && c.N > 0, "conv[%d]: bad extent", i);
+    VAM_REQUIRE(c.kh >= 1 && c.kh <= 5 && c.kw >= 1 && c.kw <= 5 && (c.stride == 1 || c.stride == 2), "conv[%d]: kernel %dx%d stride %d", i, c.kh, c.kw, c.stride);
+    VAM_REQUIRE(c.wpack && c.out, "conv[%d]: null weights/output", i);
+    int cin = 0;
+    for (int s = 0; s < VAM_MAX_SEG; ++s) {
+      if (s < c.n_seg) {
+        VAM_REQUIRE(c.seg[s].ptr && c.seg[s].C > 0 && c.seg[s].ld >= c.seg[s].C, "conv[%d]: segment %d invalid", i, s);
+        VAM_REQUIRE((c.seg[s].ld % 4) == 0 && (((uintptr_t)c.seg[s].ptr) % 16) == 0, "conv[%d]: segment %d not 16-byte aligned", i, s);
+        cin += c.seg[s].C;
+        p.seg_ptr[s] = c.seg[s].ptr;
+        p.seg_ld[s] = c.seg[s].ld;
+        p.seg_end[s] = cin;
+      } else {
+        p.seg_ptr[s] = nullptr;
+        p.seg_ld[s] = 0;
+        p.seg_end[s] = 1 << 30;
+      }
+    }
+    int pbk = bk_for(cin);
+    VAM_REQUIRE(cin % 4 == 0, "conv[%d]: Cin %d not a multiple of 4", i, cin);
+    for (int s = 0; s + 1 < c.n_seg; ++s)
+      VAM_REQUIRE(p.seg_end[s] % pbk == 0, "conv[%d]: segment boundary %d not a multiple of BK=%d", i, p.seg_end[s], pbk);
+    if (i == 0) bk = pbk;
+    VAM_REQUIRE(pbk == bk, "conv group mixes BK=%d and BK=%d problems", bk, pbk);
+    // the last input position touched must be consistent with the declared geometry
+    VAM_REQUIRE((c.Ho - 1) * c.stride - c.pad_y <= c.H - 1 + c.kh && (c.Wo - 1) * c.stride - c.pad_x <= c.W - 1 + c.kw, "conv[%d]: output grid larger than the input allows", i);
+    if (c.flags & VAM_CONV_PS2) {
+      VAM_REQUIRE(c.Cq > 0 && c.N == 4 * c.Cq && c.Hf == 2 * c.Ho && c.Wf == 2 * c.Wo, "conv[%d]: PS2 geometry", i);
+    } else {
+      VAM_REQUIRE(c.osy >= 1 && c.osx >= 1 && c.ooy >= 0 && c.oox >= 0 && (c.Ho - 1) * c.osy + c.ooy < c.Hf && (c.Wo - 1) * c.osx + c.oox < c.Wf, "conv[%d]: output placement outside Hf x Wf", i);
+    }
+    VAM_REQUIRE(c.N % 4 == 0, "conv[%d]: N %d not a multiple of 4", i, c.N);
+    {
+      const bool vec = !(c.flags & VAM_CONV_OUT_NCHW) && (!(c.flags & VAM_CONV_PS2) || (c.Cq % 4) == 0);
+      auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+      if (vec) {
+        VAM_REQUIRE(c.ldo % 4 == 0 && al(c.out) && al(c.bias), "conv[%d]: output/bias not 16-byte aligned", i);
+        VAM_REQUIRE((!c.pre.ptr || (c.pre.ld % 4 == 0 && al(c.pre.ptr))) && (!c.mul.ptr || (c.mul.ld % 4 == 0 && al(c.mul.ptr))) &&
+                    (!c.post.ptr || (c.post.ld % 4 == 0 && al(c.post.ptr))) && (!c.post2.ptr || (c.post2.ld % 4 == 0 && al(c.post2.ptr))),
+                    "conv[%d]: epilogue operand not 16-byte aligned", i);
+      }
+    }
+    if (!(c.flags & VAM_CONV_OUT_NCHW)) VAM_REQUIRE(c.ldo >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N), "conv[%d]: ldo %d < channels", i, c.ldo);
+    p.n_seg = c.n_seg;
+    p.H = c.H; p.W = c.W; p.HW = c.H * c.W;
+    p.kh = c.kh; p.kw = c.kw; p.stride = c.stride; p.pad_y = c.pad_y; p.pad_x = c.pad_x;
+    p.Ho = c.Ho; p.Wo = c.Wo; p.HoWo = c.Ho * c.Wo;
+    long P = (long)c.B * c.Ho * c.Wo;
+    VAM_REQUIRE(P < (1L << 30) && (long)c.B * c.H * c.W < (1L << 30), "conv[%d]: too many pixels", i);
+    p.P = (int)P;
+    p.N = c.N; p.Npad = (c.N + 31) / 32 * 32;
+    p.Cin = cin; p.Kc = (cin + pbk - 1) / pbk;
+    p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
+    p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
+    p.Cq = c.Cq; p.act = c.act; p.flags = c.flags;
+    p.pre = c.pre.ptr; p.ld_pre = c.pre.ld;
+    p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
+    p.post = c.post.ptr; p.ld_post = c.post.ld;
+    p.post2 = c.post2.ptr; p.ld_post2 = c.post2.ld;
+    if (P > max_p) max_p = P;
+    if (c.N > max_n) max_n = c.N;
+    flops += 2.0 * (double)P * c.N * cin * c.kh * c.kw;
+    bytes += 4.0 * ((double)c.B * c.H * c.W * cin + (double)P * c.N + (double)c.kh * c.kw * cin * c.N);
+  }
+  // tile choice: one configuration per launch, driven by the widest problem
+  int cfg;  // 0:128x128  1:128x64  2:64x64  3:128x32  4:64x32
+  long work128 = 0;
+  for (int i = 0; i < nprob; ++i) work128 += (long)cdiv(ga.p[i].P, 128) * cdiv(ga.p[i].Npad, 128);
+  if (max_n <= 32) cfg = (cdiv(max_p, 128) * (long)nprob >= 512) ? 3 : 4;
+  else if (max_n <= 64) cfg = (cdiv(max_p, 128) * (long)nprob >= 512) ? 1 : 2;
+  else if (work128 >= 384) cfg = 0;
+  else if (work128 * 2 >= 384) cfg = 1;
+  else cfg = 2;
+  static const int BMs[5] = {128, 128, 64, 128, 64}, BNs[5] = {128, 64, 64, 32, 32};
+  int total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    ga.tile_start[i] = total;
+    ga.p[i].tiles_n = cdiv(ga.p[i].Npad, BNs[cfg]);
+    total += cdiv(ga.p[i].P, BMs[cfg]) * ga.p[i].tiles_n;
+  }
+  for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
+  if (bk == 32) {
+    switch (cfg) {
+      case 0: return launch_cfg<128, 128, 32, 2, 2>(ga, total, s);
+      case 1: return launch_cfg<128, 64, 32, 2, 2>(ga, total, s);
+      case 2: return launch_cfg<64, 64, 32, 2, 2>(ga, total, s);
+      case 3: return launch_cfg<128, 32, 32, 4, 1>(ga, total, s);
+      default: return launch_cfg<64, 32, 32, 2, 1>(ga, total, s);
+    }
+  } else {
+    switch (cfg) {
+      case 0: return launch_cfg<128, 128, 16, 2, 2>(ga, total, s);
+      case 1: return launch_cfg<128, 64, 16, 2, 2>(ga, total, s);
+      case 2: return launch_cfg<64, 64, 16, 2, 2>(ga, total, s);
+      case 3: return launch_cfg<128, 32, 16, 4, 1>(ga, total, s);
+      default: return launch_cfg<64, 32, 16, 2, 1>(ga, total, s);
+    }
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+"""Execution plans: the reference's module graph lowered to libvampic launches.
+
+A :class:`Plan` owns every NHWC buffer it needs (allocated while the plan is built,
+never while it runs) and a flat list of pre-marshalled C-ABI calls.  ``run()`` replays
+them on the current HIP stream; ``graph()`` captures the replay once into a hipGraph so
+a steady-state step is a single ``hipGraphLaunch``.
+
+Lowering rules (reference lines in brackets)
+  * torch.cat of supports never happens: a conv problem reads up to 4 channel windows
+    [pic.py:528-529,548,598-599,635];
+  * GELU / LeakyReLU / 0.5*tanh / sigmoid-gate / residual adds / GDN's x*rsqrt(.) /
+    clamp(0,1) / PixelShuffle are conv epilogues [layers.py:30-86, gdn.py:62-75, rem.py:52-66];
+  * structurally identical, mutually independent stacks run in lockstep as grouped
+    launches: the two encoders, the four hyper-synthesis stacks, the (mean, scale) pair of a
+    slice, base slices 5..9, and the ten progressive LRP stacks [SURVEY §3b].
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import layers as Ly
+from . import ops
+from .ops import View
+
+
+class Plan:
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self.steps: List[Callable[[], None]] = []
+        self.keep: List[object] = []          # buffers / ctypes arrays referenced by the steps
+        self._graph: Optional[ops.Graph] = None
+        self.flops = 0.0
+
+    # ---- buffers
+    def buf(self, B, H, W, C, zero=False) -> View:
+        v = ops.new_view(B, H, W, C, self.device, zero=zero)
+        self.keep.append(v.buf)
+        return v
+
+    # ---- recorded launches
+    def conv(self, problems: Sequence[L.VamConv]):
+        lib = L.load()
+        for i in range(0, len(problems), L.VAM_MAX_GROUP):
+            chunk = list(problems[i:i + L.VAM_MAX_GROUP])
+            arr = (L.VamConv * len(chunk))(*chunk)
+            n = len(chunk)
+            self.keep.append(arr)
+            for c in chunk:
+                cin = sum(c.seg[k].C for k in range(c.n_seg))
+                self.flops += 2.0 * c.B * c.Ho * c.Wo * c.N * cin * c.kh * c.kw
+            self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
+
+    def call(self, fn: Callable[[], None]):
+        self.steps.append(fn)
+
+    # ---- execution
+    def run(self):
+        for s in self.steps:
+            s()
+
+    def graph_run(self):
+        if self._graph is None:
+            self.run()                       # warm every kernel (lazy code-object load) before capture
+            torch.cuda.current_stream().synchronize()
+            g = ops.Graph()
+            g.capture(self.run)
+            self._graph = g
+        self._graph.launch()
+
+
+# =============================================================================
+# building blocks (each appends launches to a plan)
+# =============================================================================
+def _act_after(seq: nn.Sequential, i: int) -> int:
+    nxt = seq[i + 1] if i + 1 < len(seq) else None
+    if isinstance(nxt, Ly.GELU):
+        return L.ACT_GELU
+    if isinstance(nxt, Ly.LeakyReLU):
+        return L.ACT_LEAKY
+    return L.ACT_NONE
+
+
+def conv_layers(seq: nn.Sequential):
+    """[(layer, act)] for a conv/GELU/subpel Sequential."""
+    out = []
+    for i, m in enumerate(seq):
+        if isinstance(m, (Ly.Conv2d, Ly.SubpelConv)):
+            out.append((m, _act_after(seq, i)))
+        elif not isinstance(m, Ly._Marker):
+            raise TypeError(f"unexpected {type(m).__name__} in a conv stack")
+    return out
+
+
+def _out_extent(m, v: View):
+    if isinstance(m, Ly.SubpelConv):
+        return 2 * v.H, 2 * v.W, m.out_ch
+    if m.is_rgb_s2d:                       # runs as a 3x3 s1 problem on the space-to-depth grid
+        return v.H, v.W, m.out_channels
+    s = m.stride
+    k = m.kernel_size
+    if s == 1:
+        return v.H, v.W, m.out_channels
+    return (v.H + 2 * (k // 2) - k) // s + 1, (v.W + 2 * (k // 2) - k) // s + 1, m.out_channels
+
+
+def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[Sequence[View]],
+                 outs: Sequence[Optional[View]], final: Optional[Sequence[dict]] = None) -> List[View]:
+    """Run K structurally identical conv stacks in lockstep: layer d of every stack is one
+    grouped launch.  ``final[k]`` = extra epilogue kwargs (act/pre/mul/post/post2) of the last
+    layer of stack k.  Returns the output views."""
+    K = len(stacks)
+    lay = [conv_layers(s) for s in stacks]
+    depth = len(lay[0])
+    assert all(len(l) == depth for l in lay)
+    cur: List[Sequence[View]] = [list(i) for i in inputs]
+    res: List[View] = []
+    for d in range(depth):
+        probs = []
+        nxt = []
+        for k in range(K):
+            m, act = lay[k][d]
+            v0 = cur[k][0]
+            Ho, Wo, Co = _out_extent(m, v0)
+            last = d == depth - 1
+            if last and outs[k] is not None:
+                o = outs[k]
+            else:
+                o = plan.buf(v0.B, Ho, Wo, Co)
+            kw = {}
+            if last and final is not None and final[k]:
+                kw = dict(final[k])
+                act = kw.pop("act", act)
+            probs.append(ops.conv_problem(m.packed(), cur[k], o, act, **kw))
+            nxt.append([o])
+            if last:
+                res.append(o)
+        plan.conv(probs)
+        cur = nxt
+    return res
+
+
+def lower_gdn(plan: Plan, mods: Sequence[Ly.GDN], xs: Sequence[View], outs: Sequence[Optional[View]]) -> List[View]:
+    probs, res = [], []
+    for m, x, o in zip(mods, xs, outs):
+        o = o if o is not None else plan.buf(x.B, x.H, x.W, x.C)
+        probs.append(ops.conv_problem(m.packed(), [x], o, L.ACT_SQRT if m.inverse else L.ACT_RSQRT, mul=x,
+                                      flags=L.CONV_SQUARE_IN))
+        res.append(o)
+    plan.conv(probs)
+    return res
+
+
+def lower_residual_units(plan: Plan, mods: Sequence[Ly.ResidualUnit], xs: Sequence[View]) -> List[View]:
+    """out = GELU(conv(x) + x)  (layers/layers.py:43-48), K units in lockstep."""
+    fin = [dict(act=L.ACT_GELU, pre=x) for x in xs]
+    return lower_stacks(plan, [m.conv for m in mods], [[x] for x in xs], [None] * len(mods), fin)
+
+
+def lower_win_attention(plan: Plan, mods: Sequence[Ly.WinBasedAttention], xs: Sequence[View]) -> List[View]:
+    """x + proj(window_attention(qkv(x)))  (layers/win_attention.py:153-207)."""
+    qkvs = [plan.buf(x.B, x.H, x.W, 3 * x.C) for x in xs]
+    plan.conv([ops.conv_problem(m.attn.qkv.packed(), [x], q) for m, x, q in zip(mods, xs, qkvs)])
+    atts = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
+    for m, q, a, x in zip(mods, qkvs, atts, xs):
+        tab = m.attn.relative_position_bias_table
+        plan.keep.append(tab)
+        plan.call(lambda q=q, a=a, tab=tab, C_=x.C, h=m.num_heads, ws=m.window_size, sh=m.shift_size:
+                  ops.win_attention(q, a, tab, C_, h, ws, sh))
+    outs = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
+    plan.conv([ops.conv_problem(m.attn.proj.packed(), [a], o, post=x) for m, a, o, x in zip(mods, atts, outs, xs)])
+    return outs
+
+
+def lower_attention_blocks(plan: Plan, mods: Sequence[Ly.Win_noShift_Attention], xs: Sequence[View],
+                           outs: Sequence[Optional[View]]) -> List[View]:
+    """out = a * sigmoid(b) + x  (layers/layers.py:68-74); branch a and branch b's residual
+    units are independent, so they share launches."""
+    K = len(mods)
+    b = lower_win_attention(plan, [m.conv_b[0] for m in mods], xs)
+    a = list(xs)
+    for i in range(3):
+        r = lower_residual_units(plan, [m.conv_a[i] for m in mods] + [m.conv_b[i + 1] for m in mods], a + b)
+        a, b = r[:K], r[K:]
+    res, probs = [], []
+    for m, av, bv, x, o in zip(mods, a, b, xs, outs):
+        o = o if o is not None else plan.buf(x.B, x.H, x.W, x.C)
+        probs.append(ops.conv_problem(m.conv_b[4].packed(), [bv], o, L.ACT_SIGMOID, mul=av, post=x))
+        res.append(o)
+    plan.conv(probs)
+    return res
+
+
+def lower_deconv(plan: Plan, mods: Sequence[Ly.ConvTranspose2d], xs: Sequence[View], outs: Sequence[Optional[View]],
+                 act: int = L.ACT_NONE, out_nchw: Optional[Sequence[torch.Tensor]] = None) -> List[Optional[View]]:
+    probs, res = [], []
+    for i, (m, x) in enumerate(zip(mods, xs)):
+        o = outs[i]
+        nchw = out_nchw[i] if out_nchw is not None else None
+        if o is None and nchw is None:
+            o = plan.buf(x.B, 2 * x.H, 2 * x.W, m.out_channels)
+        for pk in m.packed():
+            probs.append(ops.conv_problem(pk, [x], o, act, out_nchw=nchw))
+        res.append(o)
+    plan.conv(probs)
+    return res
+
+
+def lower_g_a(plan: Plan, encs: Sequence[nn.Sequential], x_s2d: View, ys: Sequence[View]):
+    """models/builder.py:43-53, both encoders in lockstep; ys = 320-channel windows of y."""
+    K = len(encs)
+    t = lower_stacks(plan, [nn.Sequential(e[0]) for e in encs], [[x_s2d]] * K, [None] * K)
+    t = lower_gdn(plan, [e[1] for e in encs], t, [None] * K)
+    t = lower_stacks(plan, [nn.Sequential(e[2]) for e in encs], [[v] for v in t], [None] * K)
+    t = lower_gdn(plan, [e[3] for e in encs], t, [None] * K)
+    t = lower_attention_blocks(plan, [e[4] for e in encs], t, [None] * K)
+    t = lower_stacks(plan, [nn.Sequential(e[5]) for e in encs], [[v] for v in t], [None] * K)
+    t = lower_gdn(plan, [e[6] for e in encs], t, [None] * K)
+    t = lower_stacks(plan, [nn.Sequential(e[7]) for e in encs], [[v] for v in t], [None] * K)
+    return lower_attention_blocks(plan, [e[8] for e in encs], t, ys)
+
+
+def lower_g_s(plan: Plan, decs: Sequence[nn.Sequential], ys: Sequence[View], x_hat: Sequence[torch.Tensor],
+              clamp: bool = True):
+    """models/builder.py:8-18 (+ clamp_(0,1) of pic.py:558,651), result stored NCHW."""
+    K = len(decs)
+    t = lower_attention_blocks(plan, [d[0] for d in decs], ys, [None] * K)
+    t = lower_deconv(plan, [d[1] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[2] for d in decs], t, [None] * K)
+    t = lower_deconv(plan, [d[3] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[4] for d in decs], t, [None] * K)
+    t = lower_attention_blocks(plan, [d[5] for d in decs], t, [None] * K)
+    t = lower_deconv(plan, [d[6] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[7] for d in decs], t, [None] * K)
+    lower_deconv(plan, [d[8] for d in decs], t, [None] * K, L.ACT_CLAMP01 if clamp else L.ACT_NONE, out_nchw=x_hat)
+
+
+def lower_rem_resblocks(plan: Plan, blocks: Sequence[Ly.ResidualBlock], ins: Sequence[Sequence[View]],
+                        outs: Sequence[Optional[View]], final: Optional[Sequence[dict]] = None) -> List[View]:
+    """LeakyReLU(conv2(LeakyReLU(conv1(x)))) + skip(x)   (layers/rem.py:52-66), K blocks in lockstep.
+    ``final``: extra mul/post applied after the residual add is NOT expressible in one
+    epilogue, so callers needing it (the REM tail) pass it to :func:`lower_rem_block`."""
+    K = len(blocks)
+    x0 = [i[0] for i in ins]
+    h = [plan.buf(v.B, v.H, v.W, b.conv1.out_channels) for b, v in zip(blocks, x0)]
+    probs = [ops.conv_problem(b.conv1.packed(), i, o, L.ACT_LEAKY) for b, i, o in zip(blocks, ins, h)]
+    idn: List[View] = []
+    for b, i in zip(blocks, ins):
+        if b.skip is not None:
+            s = plan.buf(i[0].B, i[0].H, i[0].W, b.skip.out_channels)
+            probs.append(ops.conv_problem(b.skip.packed(), i, s))
+            idn.append(s)
+        else:
+            assert len(i) == 1
+            idn.append(i[0])
+    plan.conv(probs)
+    res, probs = [], []
+    for k, (b, hv) in enumerate(zip(blocks, h)):
+        o = outs[k] if outs[k] is not None else plan.buf(hv.B, hv.H, hv.W, b.conv2.out_channels)
+        probs.append(ops.conv_problem(b.conv2.packed(), [hv], o, L.ACT_LEAKY, post=idn[k]))
+        res.append(o)
+    plan.conv(probs)
+    return res
+
+
+def lower_rem_blocks(plan: Plan, mods: Sequence[Ly.LatentRateReduction], y_cks: Sequence[View],
+                     ep_bases: Sequence[Sequence[View]], ep_progs: Sequence[Sequence[View]], atts: Sequence[View],
+                     outs: Sequence[Sequence[View]]):
+    """K REM blocks in lockstep:  res = identity + enc(cat(f_latent, f_ent_base, f_ent_prog)) * att_mask
+    (layers/rem.py:130-141).  ep_progs[k] = [mu, sigma] windows (identity = their concat);
+    atts[k] = the N-channel mask, applied to both halves (rem_pic.py:194-195);
+    outs[k] = [mu', sigma'] windows."""
+    K = len(mods)
+    m0 = mods[0]
+    assert all(m.mu_std for m in mods), "lowering is built for mu_std=True (README config)"
+    names = ["enc_base_rep", "enc_progressive_entropy_params", "enc_base_entropy_params"]
+    cur: List[Sequence[View]] = [[y] for y in y_cks] + [list(e) for e in ep_progs] + [list(e) for e in ep_bases]
+    for d in range(len(m0.enc_base_rep)):
+        blocks = [getattr(m, n)[d] for n in names for m in mods]
+        r = lower_rem_resblocks(plan, blocks, cur, [None] * (3 * K))
+        cur = [[v] for v in r]
+    t: List[Sequence[View]] = [[cur[k][0], cur[2 * K + k][0], cur[K + k][0]] for k in range(K)]  # latent, base, prog
+    for d in range(len(m0.enc)):
+        r = lower_rem_resblocks(plan, [m.enc[d] for m in mods], t, [None] * K)
+        t = [[v] for v in r]
+    N = m0.dim_block
+    pk = _identity_pack(N, t[0][0].buf.device)
+    probs = []
+    for k in range(K):
+        ret = t[k][0]
+        assert ret.C == 2 * N
+        for half, (idv, o) in enumerate(zip(ep_progs[k], outs[k])):
+            probs.append(ops.conv_problem(pk, [ret.window(half * N, N)], o, L.ACT_NONE, mul=atts[k], post=idv))
+    plan.conv(probs)
+
+
+_ONE_BY_ONE: Dict[tuple, ops.Packed] = {}
+
+
+def _identity_pack(C: int, device) -> ops.Packed:
+    """1x1 identity weights: lets ``o = i + r * a`` reuse the conv epilogue (exact: 1.0*r plus zeros)."""
+    key = (C, str(device))
+    if key not in _ONE_BY_ONE:
+        w = torch.eye(C, dtype=torch.float32, device=device).reshape(C, C, 1, 1)
+        _ONE_BY_ONE[key] = ops.pack_conv(w, None, 1)
+    return _ONE_BY_ONE[key]
+
+
+# =============================================================================
+# stand-alone execution of one module on NCHW tensors (reference harness surface)
+# =============================================================================
+def run_module(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    Ly._no_autograd(x, *list(m.parameters()))
+    L.require_gpu()
+    plan = Plan(x.device)
+    if isinstance(m, Ly.TransformStack) and isinstance(m[0], Ly.Conv2d) and m[0].is_rgb_s2d:
+        xin = ops.s2d_input(x)
+        y = plan.buf(xin.B, xin.H // 8, xin.W // 8, m[7].out_channels)
+        lower_g_a(plan, [m], xin, [y])
+        plan.run()
+        return y.torch_nchw()
+    if isinstance(m, Ly.TransformStack):
+        v = ops.from_nchw(x)
+        out = torch.empty((v.B, m[8].out_channels, v.H * 16, v.W * 16), dtype=torch.float32, device=x.device)
+        lower_g_s(plan, [m], [v], [out], clamp=False)
+        plan.run()
+        return out
+    if isinstance(m, Ly.Conv2d) and m.is_rgb_s2d:
+        xin = ops.s2d_input(x)
+        o = lower_stacks(plan, [nn.Sequential(m)], [[xin]], [None])[0]
+    else:
+        v = ops.from_nchw(x)
+        if isinstance(m, (Ly.Conv2d, Ly.SubpelConv)):
+            o = lower_stacks(plan, [nn.Sequential(m)], [[v]], [None])[0]
+        elif isinstance(m, Ly.ConvStack):
+            o = lower_stacks(plan, [m], [[v]], [None])[0]
+        elif isinstance(m, Ly.ConvTranspose2d):
+            o = lower_deconv(plan, [m], [v], [None])[0]
+        elif isinstance(m, Ly.GDN):
+            o = lower_gdn(plan, [m], [v], [None])[0]
+        elif isinstance(m, Ly.ResidualUnit):
+            o = lower_residual_units(plan, [m], [v])[0]
+        elif isinstance(m, Ly.WinBasedAttention):
+            o = lower_win_attention(plan, [m], [v])[0]
+        elif isinstance(m, Ly.Win_noShift_Attention):
+            o = lower_attention_blocks(plan, [m], [v], [None])[0]
+        else:
+            raise TypeError(f"no lowering for {type(m).__name__}")
+    plan.run()
+    return o.torch_nchw()
+
+
+def run_rem_module(m: Ly.LatentRateReduction, x_base, ep_base, ep_prog, att_mask) -> torch.Tensor:
+    Ly._no_autograd(x_base, ep_base, ep_prog)
+    L.require_gpu()
+    plan = Plan(x_base.device)
+    N = m.dim_block
+    vb, ve, vp, va = (ops.from_nchw(t) for t in (x_base, ep_base, ep_prog, att_mask))
+    out = plan.buf(vb.B, vb.H, vb.W, 2 * N)
+    lower_rem_blocks(plan, [m], [vb], [[ve]], [[vp.window(0, N), vp.window(N, N)]], [va.window(0, N)],
+                     [[out.window(0, N), out.window(N, N)]])
+    plan.run()
+    return out.torch_nchw()

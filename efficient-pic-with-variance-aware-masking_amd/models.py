@@ -1,0 +1,548 @@
+"""Host-side mirror of the reference's model classes (``src/models/*.py``).
+
+``get_model(args, device)``, ``models``, ``VarianceMaskingPIC`` and
+``VarianceMaskingPICREM`` keep the reference's constructor arguments, attribute names,
+sub-module tree and ``state_dict`` keys (so ``src/demo.py`` / ``src/train.py`` style
+callers and reference checkpoints map onto them), while ``forward_single_quality`` is
+lowered once per input shape into a :class:`engine.Plan` of libvampic launches
+(optionally replayed as one hipGraph).
+
+Reference: models/__init__.py:5-55, models/base.py:6-70, models/builder.py:4-136,
+models/pic.py:25-666, models/rem_pic.py:8-422.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import layers as Ly
+from . import ops
+from .entropy_models import EntropyBottleneck, GaussianConditional, get_scale_table, _NOT_BUILT
+
+
+# ----------------------------------------------------------------------------- builders
+def define_encoder(multiple_encoder, N, M, dimensions_M):
+    """models/builder.py:39-67."""
+    def one(out):
+        return Ly.TransformStack(
+            Ly.conv(3, N, 5, 2), Ly.GDN(N), Ly.conv(N, N, 5, 2), Ly.GDN(N),
+            Ly.Win_noShift_Attention(dim=N, num_heads=8, window_size=8, shift_size=4),
+            Ly.conv(N, N, 5, 2), Ly.GDN(N), Ly.conv(N, out, 5, 2),
+            Ly.Win_noShift_Attention(dim=out, num_heads=8, window_size=4, shift_size=2))
+    return nn.ModuleList(one(dimensions_M[0]) for _ in range(2)) if multiple_encoder else one(M)
+
+
+def define_decoder(multiple_decoder, N, M, dimensions_M):
+    """models/builder.py:4-32."""
+    def one():
+        d = dimensions_M[0]
+        return Ly.TransformStack(
+            Ly.Win_noShift_Attention(dim=d, num_heads=8, window_size=4, shift_size=2),
+            Ly.deconv(d, N, 5, 2), Ly.GDN(N, inverse=True), Ly.deconv(N, N, 5, 2), Ly.GDN(N, inverse=True),
+            Ly.Win_noShift_Attention(dim=N, num_heads=8, window_size=8, shift_size=4),
+            Ly.deconv(N, N, 5, 2), Ly.GDN(N, inverse=True), Ly.deconv(N, 3, 5, 2))
+    return nn.ModuleList(one() for _ in range(2)) if multiple_decoder else one()
+
+
+def _hyper_synthesis(cin, c0, cout):
+    return Ly.ConvStack(Ly.conv3x3(cin, c0), Ly.GELU(), Ly.subpel_conv3x3(c0, 224, 2), Ly.GELU(),
+                        Ly.conv3x3(224, 256), Ly.GELU(), Ly.subpel_conv3x3(256, 288, 2), Ly.GELU(),
+                        Ly.conv3x3(288, cout))
+
+
+def define_hyperprior(multiple_hyperprior, M, N, dimensions_M):
+    """models/builder.py:71-136."""
+    h_a = Ly.ConvStack(Ly.conv3x3(M, 320), Ly.GELU(), Ly.conv3x3(320, 288), Ly.GELU(), Ly.conv3x3(288, 256, stride=2),
+                       Ly.GELU(), Ly.conv3x3(256, 224), Ly.GELU(), Ly.conv3x3(224, N, stride=2))
+    if multiple_hyperprior:
+        h_mean_s = nn.ModuleList(_hyper_synthesis(N, 192, dimensions_M[0]) for _ in range(2))
+        h_scale_s = nn.ModuleList(_hyper_synthesis(N, 192, dimensions_M[0]) for _ in range(2))
+    else:
+        h_mean_s = _hyper_synthesis(N, N, M)
+        h_scale_s = _hyper_synthesis(192, 192, M)
+    return h_a, h_mean_s, h_scale_s
+
+
+def _param_stack(cin):
+    """Five conv3x3 with GELU between: cin -> 224 -> 176 -> 128 -> 64 -> 32 (models/pic.py:83-164)."""
+    widths = (cin, 224, 176, 128, 64, 32)
+    mods = []
+    for a, b in zip(widths[:-1], widths[1:]):
+        mods += [Ly.conv(a, b, kernel_size=3, stride=1), Ly.GELU()]
+    return Ly.ConvStack(*mods[:-1])
+
+
+class CompressionModel(nn.Module):
+    """models/base.py:6-70 (conv weights kaiming-normal at construction, zero biases)."""
+
+    def __init__(self, init_weights=True):
+        super().__init__()
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def update(self, force=False):
+        raise NotImplementedError(_NOT_BUILT)
+
+
+def _resize_cdf_buffers(module, prefix, names, state_dict):
+    """models/utils.py:41-93 'resize_if_empty': let checkpoints carrying CDF tables load."""
+    bufs = dict(module.named_buffers())
+    for n in names:
+        key = f"{prefix}.{n}"
+        if key in state_dict and n in bufs and bufs[n].numel() == 0:
+            bufs[n].resize_(state_dict[key].size())
+
+
+class VarianceMaskingPIC(CompressionModel):
+    """models/pic.py:25-967."""
+
+    def __init__(self, N=192, M=640, division_dimension=[320, 640], dim_chunk=32, multiple_decoder=True,
+                 multiple_encoder=True, multiple_hyperprior=True, support_progressive_slices=5, delta_encode=True,
+                 total_mu_rep=True, all_scalable=True, mask_policy="point-based-std", **kwargs):
+        super().__init__(**kwargs)
+        self.N, self.M, self.dim_chunk = N, M, dim_chunk
+        self.num_slices = int(M // dim_chunk)
+        self.multiple_encoder, self.multiple_decoder = multiple_encoder, multiple_decoder
+        self.multiple_hyperprior = multiple_hyperprior
+        self.division_channel = division_dimension[0]
+        self.division_dimension = division_dimension
+        self.support_progressive_slices = support_progressive_slices
+        self.delta_encode, self.total_mu_rep, self.all_scalable = delta_encode, total_mu_rep, all_scalable
+        self.mask_policy = mask_policy
+        self.quality_list = [0, 10]
+        self.max_support_slices = 5
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.masking = Ly.ChannelMask(mask_policy)
+        self.num_slice_cumulative_list = [p // dim_chunk for p in division_dimension]
+        self.ns0, self.ns1 = self.num_slice_cumulative_list[0], self.num_slice_cumulative_list[1]
+        d0 = division_dimension[0]
+        delta = division_dimension[1] - division_dimension[0]
+        sp1 = support_progressive_slices + 1
+
+        self.g_a = define_encoder(multiple_encoder, N, M, division_dimension)
+        self.g_s = define_decoder(multiple_decoder, N, M, division_dimension)
+        self.h_a, self.h_mean_s, self.h_scale_s = define_hyperprior(multiple_hyperprior, M, N, division_dimension)
+        nb, np_ = self.ns0, self.ns1 - self.ns0
+        self.cc_mean_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5)) for i in range(nb))
+        self.cc_scale_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5)) for i in range(nb))
+        self.lrp_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i + 1, 6)) for i in range(nb))
+        self.cc_mean_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1)) for i in range(np_))
+        self.cc_scale_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1)) for i in range(np_))
+        self.lrp_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 2, sp1 + 1)) for i in range(nb))
+        self._plans: Dict[tuple, "_FsqPlan"] = {}
+        self.use_graph = True
+
+    # ---- reference helpers kept for the harness
+    def freeze_all(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def unfreeze_decoder(self, lrp=False):
+        target = self.g_s if not self.multiple_decoder else self.g_s[1]
+        for p in target.parameters():
+            p.requires_grad = True
+        if lrp:
+            for p in self.lrp_transforms_prog.parameters():
+                p.requires_grad = True
+
+    def unfreeze_encoder(self):
+        target = self.g_s if not self.multiple_encoder else self.g_a[1]   # (sic) pic.py:189-191
+        for p in target.parameters():
+            p.requires_grad = True
+
+    def print_information(self):
+        for name in ("g_a", "h_a", "h_mean_s", "h_scale_s", "cc_mean_transforms", "cc_scale_transforms",
+                     "cc_mean_transforms_prog", "cc_scale_transforms_prog", "lrp_transforms", "g_s"):
+            print(f" {name}: ", sum(p.numel() for p in getattr(self, name).parameters()))
+        tr = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        print(" trainable parameters: ", tr)
+        print(" freeze parameterss: ", sum(p.numel() for p in self.parameters() if not p.requires_grad))
+        return tr
+
+    def update(self, scale_table=None, force=True):
+        """Sets the scale table (needed by build_indexes); the CDF tables are the bitstream layer."""
+        if scale_table is None:
+            scale_table = get_scale_table()
+        self.gaussian_conditional.update_scale_table([float(s) for s in scale_table])
+        return True
+
+    def load_state_dict(self, state_dict, strict=True):
+        _resize_cdf_buffers(self.gaussian_conditional, "gaussian_conditional",
+                            ["_quantized_cdf", "_offset", "_cdf_length", "scale_table"], state_dict)
+        _resize_cdf_buffers(self.entropy_bottleneck, "entropy_bottleneck",
+                            ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
+        self._plans.clear()
+        return nn.Module.load_state_dict(self, state_dict, strict=strict)
+
+    def _apply(self, fn, *a, **k):
+        self._plans.clear()
+        return super()._apply(fn, *a, **k)
+
+    def define_quality(self, quality):
+        if quality is None:
+            return self.quality_list
+        if isinstance(quality, list):
+            return quality if quality[0] == 0 else [0] + quality
+        return [quality]
+
+    def determine_support(self, y_hat_base, current_index, y_hat_quality):
+        bi = y_hat_base[current_index]
+        if current_index == 0 or self.support_progressive_slices == 0:
+            return [bi]
+        s = min(self.support_progressive_slices, current_index)
+        return [bi] + y_hat_quality[current_index - s:current_index]
+
+    def merge(self, y_base, y_enhanced):
+        return y_base + y_enhanced
+
+    def compute_hyperprior(self, y, quality=10):
+        """models/pic.py:278-298 on NCHW tensors (module-level path of the harness)."""
+        z = self.h_a(y)
+        z_hat, z_lik = self.entropy_bottleneck(z, training=False)
+        if not self.multiple_hyperprior:
+            return self.h_mean_s(z_hat), self.h_scale_s(z_hat), z_lik
+        if quality == 0:
+            return self.h_mean_s[0](z_hat), self.h_scale_s[0](z_hat), z_lik
+        means = torch.cat([self.h_mean_s[0](z_hat), self.h_mean_s[1](z_hat)], dim=1)
+        scales = torch.cat([self.h_scale_s[0](z_hat), self.h_scale_s[1](z_hat)], dim=1)
+        return means, scales, z_lik
+
+    # ---- the hot path
+    def _check_config(self):
+        ok = (self.multiple_encoder and self.multiple_decoder and self.multiple_hyperprior and self.delta_encode
+              and self.total_mu_rep and self.all_scalable and self.dim_chunk == 32 and self.ns1 == 2 * self.ns0
+              and self.support_progressive_slices == 5)
+        if not ok:
+            raise NotImplementedError("the fused plan is built for the reference's README configuration "
+                                      "(dual encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable, "
+                                      "dim_chunk 32, division [d, 2d], 5 support slices)")
+
+    def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None) -> "_FsqPlan":
+        B, C_, H, W = x.shape
+        if C_ != 3 or H % 64 or W % 64:
+            raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
+        key = (B, H, W, base_only, rem_idx, str(x.device))
+        p = self._plans.get(key)
+        if p is None:
+            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device)
+            self._plans[key] = p
+        return p
+
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, clone=True):
+        """models/pic.py:497-666 (eval).  Returns the reference's dict; tensors are NCHW-shaped."""
+        if training:
+            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        Ly._no_autograd(x)
+        L.require_gpu()
+        self._check_config()
+        pr = quality
+        if mask_pol == "two-levels" and quality != 0:
+            pr = 10                                   # channel_mask.py:152-153: all ones unless pr == 0
+        plan = self._plan(x, base_only=(quality == 0))
+        return plan.execute(x, pr, None, self.use_graph, clone)
+
+    def forward(self, x, quality=None, mask_pol=None, training=True):
+        """models/pic.py:301-491.  Eval only in this build: one pass per requested quality."""
+        if training:
+            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+        qs = self.define_quality(quality)
+        base = self.forward_single_quality(x, 0, mask_pol, False)
+        x_hats, y_prog, y_hat_total = [base["x_hat"].unsqueeze(0)], [], [base["y_hat"]]
+        out = None
+        for q in qs[1:]:
+            out = self.forward_single_quality(x, q, mask_pol, False)
+            x_hats.append(out["x_hat"].unsqueeze(0))
+            y_prog.append(out["likelihoods"]["y"].unsqueeze(0))
+            y_hat_total.append(out["y_hat"])
+        lik_b = base["likelihoods"]["y"]
+        return {"x_hat": torch.cat(x_hats, 0),
+                "likelihoods": {"y": lik_b, "y_prog": torch.cat(y_prog, 0) if y_prog else lik_b,
+                                "z": base["likelihoods"]["z"]},
+                "y_hat": y_hat_total, "y_base": base["y_hat"], "y_prog": out["y_hat"] if out else base["y_hat"]}
+
+    def compress(self, *a, **k):
+        raise NotImplementedError(_NOT_BUILT)
+
+    def decompress(self, *a, **k):
+        raise NotImplementedError(_NOT_BUILT)
+
+
+class VarianceMaskingPICREM(VarianceMaskingPIC):
+    """models/rem_pic.py:8-818."""
+
+    def __init__(self, N=192, M=640, division_dimension=[320, 416], dim_chunk=32, multiple_decoder=True,
+                 multiple_encoder=True, multiple_hyperprior=True, support_progressive_slices=5, delta_encode=True,
+                 total_mu_rep=True, all_scalable=True, mask_policy="point-based-std", check_levels=[0.01, 0.25, 1.75],
+                 mu_std=True, dimension="big", **kwargs):
+        super().__init__(N=N, M=M, division_dimension=division_dimension, dim_chunk=dim_chunk,
+                         multiple_decoder=multiple_decoder, multiple_encoder=multiple_encoder,
+                         multiple_hyperprior=multiple_hyperprior, support_progressive_slices=support_progressive_slices,
+                         delta_encode=delta_encode, total_mu_rep=total_mu_rep, all_scalable=all_scalable,
+                         mask_policy=mask_policy, **kwargs)
+        self.dimension = dimension
+        self.check_levels = check_levels
+        self.num_rems = len(check_levels)
+        self.enable_rem = [True] * self.num_rems
+        self.mu_std = mu_std
+        self.post_latent = nn.ModuleList(
+            nn.ModuleList(Ly.LatentRateReduction(dim_chunk=dim_chunk, mu_std=mu_std, dimension=dimension) for _ in range(10))
+            for _ in range(self.num_rems))
+
+    def unfreeze_rems(self):
+        for p in self.post_latent.parameters():
+            p.requires_grad = True
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Loads parent keys non-strictly and ``post_latent.*`` strictly, as rem_pic.py:66-78 intends
+        (the reference forgets to strip the ``post_latent.`` prefix and fails on its own checkpoints;
+        both prefixed and stripped keys are accepted here)."""
+        own = self.state_dict()
+        parent = {k: v for k, v in state_dict.items() if k in own and "post_latent" not in k}
+        res = super().load_state_dict(parent, strict=False)
+        post = {(k[len("post_latent."):] if k.startswith("post_latent.") else k): v
+                for k, v in state_dict.items() if "post_latent" in k}
+        if post:
+            self.post_latent.load_state_dict(post, strict=True)
+            self.enable_rem = [True] * self.num_rems
+        else:
+            print("This model does not have trained REMs.  self.enable_rem will be set to False")
+            self.enable_rem = [False] * self.num_rems
+        return res
+
+    def find_check_quality(self, quality):
+        """models/rem_pic.py:142-165."""
+        cl = self.check_levels
+        if quality <= cl[0]:
+            return 0, 0, -1
+        if len(cl) in (2, 3) and cl[0] < quality <= cl[1]:
+            return cl[0], cl[1], 0
+        if len(cl) == 2 and quality > cl[1]:
+            return cl[1], 10, 1
+        if len(cl) == 3 and cl[1] < quality <= cl[2]:
+            return cl[1], cl[-1], 1
+        return cl[-1], 10, -1
+
+    def _rem_index(self, quality):
+        """models/rem_pic.py:200-213."""
+        cl = self.check_levels
+        if self.num_rems == 1:
+            return 0
+        if self.num_rems == 2:
+            return 0 if cl[0] < quality <= cl[1] else 1
+        if cl[0] < quality <= cl[1]:
+            return 0
+        if cl[1] < quality <= cl[2]:
+            return 1
+        return 2
+
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, checkpoint_ref=None,
+                               clone=True):
+        return self.forward(x=x, quality=quality, mask_pol=mask_pol, training=training, checkpoint_ref=checkpoint_ref,
+                            clone=clone)
+
+    def forward(self, x, mask_pol="point-based-std", quality=0, training=True, checkpoint_ref=None, clone=True):
+        """models/rem_pic.py:229-422 (eval)."""
+        if training:
+            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        Ly._no_autograd(x)
+        L.require_gpu()
+        self._check_config()
+        if not self.mu_std:
+            raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
+        rem_idx = None
+        if quality != 0 and checkpoint_ref is not None and quality > self.check_levels[0]:
+            _, _, right = self.find_check_quality(quality)
+            if self.enable_rem[right]:
+                rem_idx = self._rem_index(quality)
+        pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
+        plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
+        return plan.execute(x, pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, clone)
+
+    def ExtractChekpointRepr(self, x, quality, rc=True, y_check=None):
+        """rem_pic.py:121-132 returns compress(...)["y_hat"]; with a lossless coder that is the
+        likelihood path's y_hat at the same quality, which is what the plan computes
+        (the host rANS detour of the reference is not needed for this tensor)."""
+        return self.forward(x, quality=quality, training=False, checkpoint_ref=y_check)["y_hat"]
+
+
+# ----------------------------------------------------------------------------- the fused plan
+class _FsqPlan:
+    """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
+
+    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device):
+        self.m, self.B, self.H, self.W = m, B, H, W
+        self.base_only, self.rem_idx = base_only, rem_idx
+        self.pr = 0.0
+        self.graphs: Dict[float, ops.Graph] = {}
+        plan = self.plan = E.Plan(device)
+        h, w = H // 16, W // 16
+        d = m.division_dimension[0]
+        ns = m.ns0
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_in = torch.empty((B, 3, H, W), **f32)
+        self.x_hat = torch.empty((B, 3, H, W), **f32)
+        self.log2sum = torch.zeros((2, B), dtype=torch.float64, device=device)   # [y, z] per image
+        plan.keep += [self.x_in, self.x_hat, self.log2sum]
+        ls_y, ls_z = self.log2sum[0], self.log2sum[1]
+        plan.call(lambda: ops.memset_zero(self.log2sum))
+
+        # ---- analysis transforms (both encoders in lockstep)                      pic.py:506-508
+        x_s2d = plan.buf(B, H // 2, W // 2, 16)
+        plan.call(lambda: L.check(L.load().vam_s2d_input(self.x_in.data_ptr(), x_s2d.ptr, B, H, W, ops.stream_ptr()),
+                                  "vam_s2d_input"))
+        y = self.y = plan.buf(B, h, w, 2 * d)
+        E.lower_g_a(plan, [m.g_a[0], m.g_a[1]], x_s2d, [y.window(0, d), y.window(d, d)])
+
+        # ---- hyperprior                                                            pic.py:278-298
+        z = plan.buf(B, h // 4, w // 4, m.N)
+        E.lower_stacks(plan, [m.h_a], [[y]], [z])
+        self.z_hat = plan.buf(B, h // 4, w // 4, m.N)
+        self.z_lik = plan.buf(B, h // 4, w // 4, m.N)
+        plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z))
+        nh = 1 if base_only else 2
+        means_h = plan.buf(B, h, w, nh * d)
+        scales_h = plan.buf(B, h, w, nh * d)
+        E.lower_stacks(plan, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)],
+                       [[self.z_hat]] * (2 * nh),
+                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
+
+        # ---- base slices                                                           pic.py:522-554
+        C = m.dim_chunk
+        yq = plan.buf(B, h, w, d)                      # round(y-mu)+mu before the LRP correction
+        yb = self.y_base = plan.buf(B, h, w, d)        # base y_hat (after LRP)
+        self.mu_b = plan.buf(B, h, w, d)
+        self.std_b = plan.buf(B, h, w, d)
+        self.lik = plan.buf(B, h, w, d if base_only else 2 * d)
+        sl = lambda v, i, n=1: v.window(i * C, n * C)
+        mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
+
+        def base_group(idx: List[int]):
+            sup = [sl(yb, 0, min(m.max_support_slices, idx[0]))] if idx[0] > 0 else []
+            E.lower_stacks(plan, [m.cc_mean_transforms[i] for i in idx] + [m.cc_scale_transforms[i] for i in idx],
+                           [[mh0] + sup] * len(idx) + [[sh0] + sup] * len(idx),
+                           [sl(self.mu_b, i) for i in idx] + [sl(self.std_b, i) for i in idx])
+            i0, n = idx[0], len(idx)
+            plan.call(lambda: ops.gauss_tail(sl(y, i0, n), sl(self.mu_b, i0, n), sl(self.std_b, i0, n),
+                                             yhat=sl(yq, i0, n), lik=sl(self.lik, i0, n), log2sum=ls_y))
+            E.lower_stacks(plan, [m.lrp_transforms[i] for i in idx], [[mh0] + sup + [sl(yq, i)] for i in idx],
+                           [sl(yb, i) for i in idx],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i)) for i in idx])
+
+        for i in range(min(ns, m.max_support_slices)):
+            base_group([i])
+        if ns > m.max_support_slices:
+            base_group(list(range(m.max_support_slices, ns)))   # slices 5..9 only see slices 0..4
+
+        if base_only:
+            E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
+            return
+
+        # ---- progressive slices                                                    pic.py:577-643
+        mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
+        self.mu_p = plan.buf(B, h, w, d)
+        self.std_p = plan.buf(B, h, w, d)
+        mu_tot = plan.buf(B, h, w, d)
+        sp = m.support_progressive_slices
+        msups, ssups = [], []
+        for j in range(ns):
+            s = min(sp, j)
+            ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else [])
+            ss = [sh1, sl(yb, j)] + ([sl(self.std_p, j - s, s)] if s else [])
+            msups.append(ms)
+            ssups.append(ss)
+            E.lower_stacks(plan, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss],
+                           [sl(self.mu_p, j), sl(self.std_p, j)])
+            plan.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)))       # pic.py:603
+
+        mu_f, std_f = self.mu_p, self.std_p
+        if rem_idx is not None:                                                       # rem_pic.py:363-377
+            self.ck = plan.buf(B, h, w, d)
+            att = plan.buf(B, h, w, d)
+            plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
+            mu_f, std_f = plan.buf(B, h, w, d), plan.buf(B, h, w, d)
+            E.lower_rem_blocks(plan, [m.post_latent[rem_idx][j] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
+                               [[sl(self.mu_b, j), sl(self.std_b, j)] for j in range(ns)],
+                               [[sl(self.mu_p, j), sl(self.std_p, j)] for j in range(ns)],
+                               [sl(att, j) for j in range(ns)],
+                               [[sl(mu_f, j), sl(std_f, j)] for j in range(ns)])
+        self.mu_f, self.std_f = mu_f, std_f
+        self.mask = plan.buf(B, h, w, d)
+        self.thr = torch.empty((B * ns,), **f32)
+        plan.keep.append(self.thr)
+        plan.call(lambda: ops.variance_mask(std_f, self.pr, self.mask, n_slice=ns, thr=self.thr))   # pic.py:621-622
+        rq = plan.buf(B, h, w, d)
+        plan.call(lambda: ops.gauss_tail(y.window(d, d), mu_f, std_f, y2=y.window(0, d), mask=self.mask, yhat=rq,
+                                         lik=self.lik.window(d, d), log2sum=ls_y))                  # pic.py:625-629
+        yp = self.y_prog = plan.buf(B, h, w, d)
+        E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
+                       [sl(yp, j) for j in range(ns)],
+                       [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)])   # :635-641
+        E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
+
+    # -------------------------------------------------------------------------------------------
+    def execute(self, x, pr, checkpoint_ref, use_graph, clone):
+        self.pr = float(pr)
+        self.x_in.copy_(x)
+        if checkpoint_ref is not None:
+            ck = ops.from_nchw(checkpoint_ref)
+            self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])
+        if use_graph:
+            g = self.graphs.get(self.pr)
+            if g is None:
+                self.plan.run()                      # warm-up: every code object loaded before capture
+                torch.cuda.current_stream().synchronize()
+                g = ops.Graph()
+                g.capture(self.plan.run)
+                if len(self.graphs) > 32:
+                    self.graphs.clear()
+                self.graphs[self.pr] = g
+            g.launch()
+        else:
+            self.plan.run()
+        fin = (lambda t: t.clone()) if clone else (lambda t: t)
+        nchw = lambda v: fin(v.torch_nchw())
+        out = {"x_hat": fin(self.x_hat),
+               "likelihoods": {"y": nchw(self.lik), "z": nchw(self.z_lik)},
+               "log2_likelihood_sum": fin(self.log2sum)}
+        if self.base_only:
+            yh = nchw(self.y_base)
+            out.update({"y_hat": yh, "y_base": yh, "y_prog": yh, "mu": nchw(self.mu_b), "std": nchw(self.std_b),
+                        "mu_base": nchw(self.mu_b), "std_base": nchw(self.std_b), "mu_prog": [], "std_prog": []})
+        else:
+            yh = nchw(self.y_prog)
+            out.update({"y_hat": yh, "y_base": nchw(self.y_base), "y_prog": yh, "mu_base": nchw(self.mu_b),
+                        "mu": nchw(self.mu_f), "std_base": nchw(self.std_b), "std": nchw(self.std_f),
+                        "mask": nchw(self.mask)})
+        return out
+
+
+models = {"pic": VarianceMaskingPIC, "rem": VarianceMaskingPICREM}
+
+
+def get_model(args, device):
+    """models/__init__.py:11-55 (``cnn`` = the legacy WACNN baseline, out of scope: SURVEY §2 #11)."""
+    common = dict(N=args.N, M=args.M, multiple_decoder=args.multiple_decoder, multiple_encoder=args.multiple_encoder,
+                  multiple_hyperprior=args.multiple_hyperprior, dim_chunk=args.dim_chunk,
+                  division_dimension=args.division_dimension, mask_policy=args.mask_policy,
+                  support_progressive_slices=args.support_progressive_slices, delta_encode=args.delta_encode,
+                  total_mu_rep=args.total_mu_rep, all_scalable=args.all_scalable)
+    if args.model == "pic":
+        net = VarianceMaskingPIC(**common)
+    elif args.model == "rem":
+        net = VarianceMaskingPICREM(**common, check_levels=args.check_levels, mu_std=args.mu_std,
+                                    dimension=args.dimension)
+    else:
+        raise NotImplementedError
+    return net.to(device)

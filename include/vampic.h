@@ -1,0 +1,215 @@
+/*
+ * libvampic — C ABI of the MI355X-native hot path of the variance-aware-masking
+ * progressive image codec (reference: das-ankur/Efficient-PIC-with-Variance-Aware-Masking).
+ *
+ * The reference has no FFI: its boundary is the Python model object
+ * (src/models/pic.py, src/models/rem_pic.py).  Each entry point below replaces the
+ * torch operator pattern cited next to it; the Python package
+ * `efficient-pic-with-variance-aware-masking_amd` binds them with ctypes and keeps the
+ * reference's module/attribute surface on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are NHWC fp32: element (b,y,x,c) of a tensor with pixel stride
+ *     `ld` lives at ptr[((b*H + y)*W + x)*ld + c]  (ld >= C lets a tensor be a channel
+ *     window of a wider buffer, which is how torch.cat is avoided);
+ *   - the caller owns every buffer; kernels are enqueued on `stream` (a hipStream_t
+ *     passed as void*), never allocate, never synchronise;
+ *   - return value 0 = ok, negative = VAM_E*; vam_last_error() gives the message of
+ *     the last failure on the calling thread.
+ */
+#ifndef VAMPIC_H
+#define VAMPIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAM_OK 0
+#define VAM_EINVAL (-1)   /* bad argument / unsupported shape */
+#define VAM_EHIP (-2)     /* a HIP runtime call failed        */
+#define VAM_ENOGPU (-3)   /* no gfx950 device visible          */
+
+const char* vam_last_error(void);
+int vam_version(void);
+/* 0 if a HIP device is usable; fills name (<=128 bytes) and CU count. */
+int vam_device_info(char* name128, int* cu_count);
+
+/* ------------------------------------------------------------------ convolution */
+
+/* activation applied to (acc + bias [+ pre]) */
+enum vam_act {
+  VAM_ACT_NONE = 0,
+  VAM_ACT_GELU = 1,      /* exact erf GELU, nn.GELU() default  (pic.py:86)          */
+  VAM_ACT_LEAKY = 2,     /* LeakyReLU(0.01)                    (layers/rem.py:41)   */
+  VAM_ACT_HALF_TANH = 3, /* 0.5*tanh(v)                        (pic.py:550,637)     */
+  VAM_ACT_SIGMOID = 4,   /*                                    (layers/layers.py:72)*/
+  VAM_ACT_CLAMP01 = 5,   /* clamp_(0,1)                        (pic.py:558,651)     */
+  VAM_ACT_RSQRT = 6,     /* GDN   (layers/gdn.py:72)                                */
+  VAM_ACT_SQRT = 7       /* IGDN  (layers/gdn.py:70)                                */
+};
+
+enum vam_conv_flags {
+  VAM_CONV_SQUARE_IN = 1,   /* operand is x*x (GDN norm pool, gdn.py:68)                 */
+  VAM_CONV_PS2 = 2,         /* phase-major output channels scattered like PixelShuffle(2):
+                               n = phase*Cq + c -> pixel (2y+phase/2, 2x+phase%2), chan c  */
+  VAM_CONV_OUT_NCHW = 4     /* store the result NCHW (model edge, x_hat)                  */
+};
+
+#define VAM_MAX_SEG 4
+
+typedef struct vam_seg {
+  const float* ptr; /* first channel of this segment at pixel (0,0,0) */
+  int32_t C;        /* channels taken from it                          */
+  int32_t ld;       /* pixel stride of the underlying buffer (floats)  */
+} vam_seg;
+
+typedef struct vam_aux {
+  const float* ptr; /* NULL = unused; indexed like the output (pixel*ld + channel) */
+  int32_t ld;
+  int32_t pad_;
+} vam_aux;
+
+/*
+ * One convolution problem:  out = post2 + post + mul * act(conv(cat(seg...)) + bias + pre)
+ * Replaces nn.Conv2d / nn.ConvTranspose2d (one sub-pixel phase per problem) /
+ * nn.Linear and the element-wise ops the reference applies around them
+ * (layers/layers.py:5-86, layers/gdn.py:62-75, layers/rem.py:52-66,130-141,
+ *  models/pic.py:528-551,598-641).
+ */
+typedef struct vam_conv {
+  vam_seg seg[VAM_MAX_SEG];
+  int32_t n_seg;
+  int32_t B, H, W;          /* input extent                                           */
+  int32_t kh, kw;           /* taps                                                   */
+  int32_t stride;           /* 1 or 2                                                 */
+  int32_t pad_y, pad_x;     /* input y = oy*stride - pad_y + ty                       */
+  int32_t Ho, Wo;           /* extent of the grid of output positions of THIS problem */
+  int32_t N;                /* output channels (packed order)                         */
+  const float* wpack;       /* from vam_pack_conv_weights (same kh,kw,Cin,N,BK)       */
+  const float* bias;        /* N floats (packed order) or NULL                        */
+  float* out;
+  int32_t ldo;              /* output pixel stride (floats)                           */
+  int32_t Hf, Wf;           /* full output extent                                     */
+  int32_t osy, osx, ooy, oox; /* output pixel = (oy*osy+ooy, ox*osx+oox) (ignored w/ PS2) */
+  int32_t Cq;               /* PS2: channels per phase (N == 4*Cq)                    */
+  int32_t act;              /* enum vam_act                                           */
+  int32_t flags;            /* enum vam_conv_flags                                    */
+  vam_aux pre, mul, post, post2;
+} vam_conv;
+
+/* Size in floats of the packed weight buffer for (kh,kw,Cin,N). */
+size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n);
+
+enum vam_pack_mode {
+  VAM_PACK_CONV = 0,     /* src OIHW [N][Cin][kh][kw]   (nn.Conv2d, nn.Linear with kh=kw=1) */
+  VAM_PACK_DECONV5S2 = 1,/* src IOHW [Cin][Cout][5][5] (layers/layers.py:14-22); builds the
+                            sub-pixel phase `phase` (0..3 = py*2+px) as a (kh,kw) in
+                            {3,2}x{3,2} correlation, or with phase = -1 the merged
+                            3x3 / N = 4*Cout phase-major form used with VAM_CONV_PS2   */
+  VAM_PACK_PS2 = 2,      /* src OIHW with O = Cq*4 in PixelShuffle order (c*4+i*2+j) ->
+                            packed n = (i*2+j)*Cq + c   (layers/layers.py:82-86)          */
+  VAM_PACK_GDN = 3       /* src gamma [N][Cin] in reparametrised storage -> max(g,2^-18)^2-2^-36
+                            (layers/gdn.py:52-66, compressai NonNegativeParametrizer)     */
+};
+/* Device-side repack of a weight tensor into the kernel's [tap][k-chunk][n][k] layout. */
+int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase,
+                          int kh, int kw, int cin, int n, void* stream);
+/* bias helpers: PS2 permutation / GDN beta reparam (max(b, sqrt(1e-6+2^-36))^2 - 2^-36) /
+ * merged-deconv replication (4x). mode as above. */
+int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
+
+/* Launch up to VAM_MAX_GROUP independent problems as ONE grid (grouped launch:
+ * e.g. the mean and scale stacks of one slice, or the four phases of a deconv). */
+#define VAM_MAX_GROUP 8
+int vam_conv_group(const vam_conv* problems, int n_problems, void* stream);
+
+/* ------------------------------------------------------------------ model edges */
+/* x NCHW [B,3,H,W] -> space-to-depth NHWC [B,H/2,W/2,16] (12 real channels (py,px,c), 4 zero)
+ * so that conv5x5 s2 (3->N) becomes a 3x3 s1 MFMA problem (layers/layers.py:5-12, builder.py:44). */
+int vam_s2d_input(const float* x_nchw, float* out, int B, int H, int W, void* stream);
+int vam_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ld_dst, void* stream);
+int vam_nhwc_to_nchw(const float* src, int ld_src, float* dst, int B, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ window attention */
+/* Swin block core (layers/win_attention.py:84-115,153-207): qkv is [B,H,W,3C] (q|k|v,
+ * heads contiguous inside each), out[b,y,x,:] = softmax(q*scale k^T + bias + shiftmask) v
+ * written at the un-shifted position; roll/partition/reverse are folded into addressing.
+ * table: relative_position_bias_table [(2ws-1)^2][heads].  ws in {4,8}. */
+int vam_win_attention(const float* qkv, int ld_qkv, float* out, int ld_out, const float* table,
+                      int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+
+/* ------------------------------------------------------------------ variance mask */
+/* ChannelMask.forward "point-based-std" (layers/channel_mask.py:132-151) for n_seg
+ * independent segments.  Segment s covers, for every pixel p < n_pix, the C channels at
+ * sigma + s_b*batch_stride ... ; element (p,c) at sigma[seg_off(s) + p*ld + c].
+ *   seg s = b*n_slice + j  ->  seg_off = b*batch_stride + j*slice_stride
+ * thr_out[s] receives the fp32 threshold (NaN if the segment holds a NaN, +inf/-inf
+ * conventions for pr==0 / pr>=10: mask all 0 / all 1).  mask_out has the layout of sigma
+ * (its own ld / strides) and receives 0.0f / 1.0f. pr is the reference's `pr` (0..10+). */
+int vam_variance_mask(const float* sigma, int ld, long batch_stride, long slice_stride,
+                      int n_batch, int n_slice, int n_pix, int C, double pr,
+                      float* mask_out, int ld_mask, long mask_batch_stride, long mask_slice_stride,
+                      float* thr_out, void* stream);
+
+/* ------------------------------------------------------------------ Gaussian conditional */
+/* Fused slice tail (models/pic.py:545-546,625-629; entropy_models.py:620-652).
+ *  base  (mask == NULL):  v = round(y-mu);           lik = L(|(v+mu)-mu|, sigma);        yhat = v+mu
+ *  prog  (mask != NULL):  r = y - ybase_raw; v = round(r-mu); in = (r-mu)*m;
+ *                         lik = L(|round(in)|, sigma*m);   yhat = v*m + mu
+ * Each tensor is a [n_pix, C] channel window with its own pixel stride. y2 (may be NULL)
+ * is subtracted from y first (delta_encode, pic.py:583-584).
+ * log2sum (may be NULL): per-batch-item sum of log2(lik) accumulated atomically
+ * (pix_per_item pixels per item) — cleared by the caller.
+ * sym (may be NULL): int32 quantised symbols (v, or v*m) for the entropy coder. */
+int vam_gauss_tail(const float* y, int ld_y, const float* y2, int ld_y2,
+                   const float* mu, int ld_mu, const float* sigma, int ld_sigma,
+                   const float* mask, int ld_mask,
+                   float* yhat, int ld_yhat, float* lik, int ld_lik,
+                   int32_t* sym, int ld_sym, double* log2sum, int pix_per_item,
+                   long n_pix, int C, void* stream);
+
+/* GaussianConditional.build_indexes (entropy_models.py:654-659): idx = 63 - #{i<63: max(s,.11) <= T_i}
+ * table: 64 floats (device). mask (may be NULL) multiplies sigma first (pic.py:809). */
+int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int ld_mask,
+                      const float* table, int n_table, int32_t* idx, int ld_idx,
+                      long n_pix, int C, void* stream);
+
+/* EntropyBottleneck eval forward (entropy_models.py:403-436,449-492) on z NHWC [n_pix, C]:
+ * zhat = round(z-med)+med ; lik = |sigmoid(s*upper)-sigmoid(s*lower)| clamped at 1e-9.
+ * params: the 15 tensors _matrix0.._4,_bias0.._4,_factor0.._3 and quantiles as stored in the
+ * state_dict, concatenated per tensor (see INTEGRATION.md for the order), C channels. */
+int vam_eb_forward(const float* z, int ld_z, const float* params, int C,
+                   float* zhat, int ld_zhat, float* lik, int ld_lik,
+                   double* log2sum, int pix_per_item, long n_pix, void* stream);
+
+/* out[p, c] = a[p, c] + b[p, c]   (channel windows) — mu_total = mu + yhat_base (pic.py:603) */
+int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out,
+            long n_pix, int C, void* stream);
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (accumulators are cleared inside the captured graph) */
+int vam_memset_zero(void* ptr, size_t bytes, void* stream);
+/* sum((a-b)^2) accumulated in double into acc[0] (PSNR, utility/functions.py:172-174) */
+int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
+
+/* ------------------------------------------------------------------ graphs / timing */
+int vam_graph_begin(void* stream);
+int vam_graph_end(void* stream, void** graph_exec_out);
+int vam_graph_launch(void* graph_exec, void* stream);
+int vam_graph_destroy(void* graph_exec);
+
+/* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).
+ * While enabled every launch is bracketed by an event pair; vam_prof_read synchronises the
+ * events and returns accumulated milliseconds / launch count / algorithmic flops & bytes. */
+enum vam_family { VAM_FAM_CONV = 0, VAM_FAM_ATTN = 1, VAM_FAM_MASK = 2, VAM_FAM_TAIL = 3,
+                  VAM_FAM_MISC = 4, VAM_FAM_COUNT = 5 };
+int vam_prof_enable(int on);
+int vam_prof_reset(void);
+int vam_prof_read(int family, double* ms, long* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMPIC_H */

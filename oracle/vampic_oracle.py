@@ -1,0 +1,505 @@
+"""CPU oracle for the variance-aware-masking codec hot path.
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package never does (it fails loudly when the HIP
+library is missing instead of falling back to anything in here).
+
+This is an independent restatement (numpy for the integer/rank arithmetic,
+plain ATen CPU ops for the dense float arithmetic) of the reference's
+``forward_single_quality`` data flow and of every operator on it.  It is
+*functional*: it takes a flat ``state_dict`` with the reference's key names and
+never instantiates an ``nn.Module``.  Each function cites the reference lines
+it follows (paths relative to ``/root/reference/src``).
+
+Pinning: ``oracle/gen_golden.py`` runs the real reference (imported from
+``/root/reference`` with the two third-party stand-ins of ``oracle/ref_stubs``)
+and this oracle on the same seeded weights/inputs and commits the reference's
+outputs under ``tests/golden``; ``tests/test_oracle_golden.py`` re-checks the
+oracle against those vectors on every run.  The arithmetic of compressai's
+``LowerBound`` / ``NonNegativeParametrizer`` is restated from the published
+CompressAI 1.2.4 definition (the package is absent offline), so those two
+helpers are pinned only through the stand-ins — see DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+from fractions import Fraction
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64  # models/pic.py:12-14
+SCALE_BOUND = 0.11          # entropy_models.py:535
+LIKELIHOOD_BOUND = 1e-9     # entropy_models.py:83
+NUM_HEADS = 8               # models/builder.py:9,14,48,52
+
+
+# --------------------------------------------------------------------------
+# A.1  variance mask  (layers/channel_mask.py:132-151, 18-49)
+# --------------------------------------------------------------------------
+def _fma32(a: np.float32, b: np.float32, c: np.float32) -> np.float32:
+    """Correctly rounded fp32 fused multiply-add a*b+c (exact rational arithmetic,
+    then one round-to-nearest-even)."""
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        with np.errstate(all="ignore"):
+            return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+    exact = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    cand = np.float32(float(exact))
+    if not np.isfinite(cand):
+        return cand
+    best, best_err = cand, abs(Fraction(float(cand)) - exact)
+    for nb in (np.nextafter(cand, np.float32(-np.inf)), np.nextafter(cand, np.float32(np.inf))):
+        if not np.isfinite(nb):
+            continue
+        err = abs(Fraction(float(nb)) - exact)
+        if err < best_err or (err == best_err and (nb.view(np.uint32) & 1) == 0 and (best.view(np.uint32) & 1) == 1):
+            best, best_err = nb, err
+    return np.float32(best)
+
+
+def quantile_threshold_np(seg: np.ndarray, q_keep: float) -> np.float32:
+    """fp32-exact restatement of ``torch.quantile(seg, 1 - q_keep)`` (linear
+    interpolation) for one flattened fp32 segment.
+
+    ``q_keep`` is the python float ``min(pr, 10) * 0.1`` of channel_mask.py:137-139.
+    ATen computes rank = float32(q) * float32(n-1), gathers the two neighbours and
+    calls lerp_, whose CPU kernel evaluates ``fma(w, b-a, a)`` for w < 0.5 and
+    ``fma(w-1, b-a, b)`` otherwise — a FUSED multiply-add (checked against
+    torch.quantile on 3120 cases: 0 mismatches fused, 7 unfused).
+    """
+    s = np.sort(seg.astype(np.float32, copy=False).ravel(), kind="stable")
+    n = s.size
+    if np.isnan(s).any():
+        return np.float32(np.nan)
+    qt = np.float32(1.0 - q_keep)               # python double -> fp32 scalar tensor
+    rank = np.float32(qt * np.float32(n - 1))   # fp32 multiply
+    lo = int(np.floor(rank))
+    hi = int(np.ceil(rank))
+    w = np.float32(rank - np.float32(lo))
+    a, b = s[lo], s[hi]
+    with np.errstate(all="ignore"):
+        d = np.float32(b - a)
+        if w < np.float32(0.5):
+            return _fma32(w, d, a)
+        return _fma32(np.float32(w - np.float32(1.0)), d, b)
+
+
+def variance_mask_np(scale: np.ndarray, pr: float) -> np.ndarray:
+    """``ChannelMask.forward(scale, pr, "point-based-std")`` for a [B, ...] fp32
+    array: one quantile per batch item over all of its elements.  Returns a
+    float32 {0,1} array of the same shape (channel_mask.py:132-151)."""
+    scale = np.asarray(scale, dtype=np.float32)
+    if pr >= 10:
+        return np.ones_like(scale)
+    if pr == 0:
+        return np.zeros_like(scale)
+    q_keep = (10 if pr > 10 else pr) * 0.1
+    out = np.empty_like(scale)
+    for b in range(scale.shape[0]):
+        thr = quantile_threshold_np(scale[b], q_keep)
+        with np.errstate(invalid="ignore"):
+            out[b] = (scale[b] >= thr).astype(np.float32)
+    return out
+
+
+def variance_mask(scale: Tensor, pr: float) -> Tensor:
+    return torch.from_numpy(variance_mask_np(scale.detach().cpu().numpy(), pr))
+
+
+def prog_mask_np(blocks: Sequence[np.ndarray], pr: float) -> np.ndarray:
+    """``ChannelMask.ProgMask`` (channel_mask.py:18-49): list of [1,C,h,w]
+    blocks -> [len, C, h, w]."""
+    res = []
+    prf = (10 if pr > 10 else pr) * 0.1
+    for blk in blocks:
+        blk = np.asarray(blk, dtype=np.float32)
+        if prf >= 1:
+            res.append(np.ones_like(blk[0]))
+        elif prf == 0:
+            res.append(np.zeros_like(blk[0]))
+        else:
+            thr = quantile_threshold_np(blk[0], prf)
+            with np.errstate(invalid="ignore"):
+                res.append((blk[0] >= thr).astype(np.float32))
+    return np.stack(res)
+
+
+# --------------------------------------------------------------------------
+# A.4 / A.5  Gaussian conditional  (entropy_models.py:573-576, 620-659)
+# --------------------------------------------------------------------------
+def scale_table() -> Tensor:
+    """models/pic.py:17-18."""
+    return torch.exp(torch.linspace(math.log(SCALES_MIN), math.log(SCALES_MAX), SCALES_LEVELS))
+
+
+def _phi_c(t: Tensor) -> Tensor:
+    return 0.5 * torch.erfc(float(-(2 ** -0.5)) * t)   # entropy_models.py:573-576
+
+
+def gaussian_likelihood(inputs: Tensor, scales: Tensor, means: Optional[Tensor]) -> Tensor:
+    """Eval-mode ``GaussianConditional.forward`` likelihood
+    (entropy_models.py:637-652 with quantize "dequantize" :140-149)."""
+    if means is not None:
+        outputs = torch.round(inputs - means) + means
+        values = outputs - means
+    else:
+        values = torch.round(inputs)
+    s = torch.clamp_min(scales, SCALE_BOUND)
+    values = values.abs()
+    lik = _phi_c((0.5 - values) / s) - _phi_c((-0.5 - values) / s)
+    return torch.clamp_min(lik, LIKELIHOOD_BOUND)
+
+
+def build_indexes(scales: Tensor, table: Optional[Tensor] = None) -> Tensor:
+    """entropy_models.py:654-659."""
+    table = scale_table() if table is None else table
+    s = torch.clamp_min(scales, SCALE_BOUND)
+    idx = torch.full(s.shape, len(table) - 1, dtype=torch.int32)
+    for t in table[:-1]:
+        idx -= (s <= t).int()
+    return idx
+
+
+# --------------------------------------------------------------------------
+# A.6  factorised prior for z  (entropy_models.py:403-436, 449-492)
+# --------------------------------------------------------------------------
+def eb_logits_cumulative(sd: SD, v: Tensor, prefix: str = "entropy_bottleneck.") -> Tensor:
+    logits = v
+    for i in range(5):
+        logits = torch.matmul(F.softplus(sd[f"{prefix}_matrix{i}"]), logits)
+        logits = logits + sd[f"{prefix}_bias{i}"]
+        if i < 4:
+            logits = logits + torch.tanh(sd[f"{prefix}_factor{i}"]) * torch.tanh(logits)
+    return logits
+
+
+def eb_forward(sd: SD, z: Tensor, prefix: str = "entropy_bottleneck."):
+    """Eval-mode ``EntropyBottleneck.forward``: returns (z_hat, likelihood)."""
+    B, C = z.shape[:2]
+    med = sd[f"{prefix}quantiles"][:, :, 1:2]              # [C,1,1]
+    vals = z.transpose(0, 1).contiguous().reshape(C, 1, -1)
+    out = torch.round(vals - med) + med
+    lower = eb_logits_cumulative(sd, out - 0.5, prefix)
+    upper = eb_logits_cumulative(sd, out + 0.5, prefix)
+    sign = -torch.sign(lower + upper)
+    lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    lik = torch.clamp_min(lik, LIKELIHOOD_BOUND)
+    shp = (C, B) + tuple(z.shape[2:])
+    return (out.reshape(shp).transpose(0, 1).contiguous(),
+            lik.reshape(shp).transpose(0, 1).contiguous())
+
+
+# --------------------------------------------------------------------------
+# layers  (layers/layers.py, layers/gdn.py, layers/win_attention.py, layers/rem.py)
+# --------------------------------------------------------------------------
+def nonneg(p: Tensor, minimum: float) -> Tensor:
+    """compressai NonNegativeParametrizer.forward."""
+    pedestal = torch.tensor([(2.0 ** -18) ** 2], dtype=torch.float32)
+    bound = torch.tensor([(minimum + (2.0 ** -18) ** 2) ** 0.5], dtype=torch.float32)
+    return torch.max(p, bound) ** 2 - pedestal
+
+
+def gdn(sd: SD, pre: str, x: Tensor, inverse: bool) -> Tensor:
+    """layers/gdn.py:62-75."""
+    C = x.shape[1]
+    beta = nonneg(sd[pre + "beta"], 1e-6)
+    gamma = nonneg(sd[pre + "gamma"], 0.0).reshape(C, C, 1, 1)
+    norm = F.conv2d(x ** 2, gamma, beta)
+    norm = torch.sqrt(norm) if inverse else torch.rsqrt(norm)
+    return x * norm
+
+
+def conv_k(sd: SD, pre: str, x: Tensor, stride: int = 1) -> Tensor:
+    w = sd[pre + "weight"]
+    return F.conv2d(x, w, sd[pre + "bias"], stride=stride, padding=w.shape[-1] // 2)
+
+
+def deconv_k(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """layers/layers.py:14-22 (k5 s2 pad2 outpad1)."""
+    w = sd[pre + "weight"]
+    k = w.shape[-1]
+    return F.conv_transpose2d(x, w, sd[pre + "bias"], stride=2, padding=k // 2, output_padding=1)
+
+
+def residual_unit(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """layers/layers.py:30-48."""
+    o = F.gelu(conv_k(sd, pre + "conv.0.", x))
+    o = F.gelu(conv_k(sd, pre + "conv.2.", o))
+    o = conv_k(sd, pre + "conv.4.", o)
+    return F.gelu(o + x)
+
+
+def _rel_pos_index(ws: int) -> Tensor:
+    """win_attention.py:63-72 (own derivation: index = (dy+ws-1)*(2ws-1) + (dx+ws-1))."""
+    ys, xs = np.divmod(np.arange(ws * ws), ws)
+    dy = ys[:, None] - ys[None, :] + ws - 1
+    dx = xs[:, None] - xs[None, :] + ws - 1
+    return torch.from_numpy(dy * (2 * ws - 1) + dx).long()
+
+
+def _shift_mask(H: int, W: int, ws: int, shift: int) -> Tensor:
+    """win_attention.py:161-177: region ids on the *shifted* grid, 0 / -100."""
+    def ids(n):
+        r = np.zeros(n, dtype=np.int64)
+        r[n - ws:n - shift] = 1
+        r[n - shift:] = 2
+        return r
+    img = ids(H)[:, None] * 3 + ids(W)[None, :]
+    win = img.reshape(H // ws, ws, W // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+    diff = win[:, None, :] - win[:, :, None]
+    return torch.from_numpy(np.where(diff != 0, -100.0, 0.0).astype(np.float32))
+
+
+def win_attention(sd: SD, pre: str, x: Tensor, ws: int, shift: int) -> Tensor:
+    """``WinBasedAttention.forward`` (win_attention.py:153-207) + ``WindowAttention``
+    (:84-115).  x: [B,C,H,W] -> shortcut + attention."""
+    B, C, H, W = x.shape
+    hd = C // NUM_HEADS
+    t = x.permute(0, 2, 3, 1)
+    if shift > 0:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    win = t.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    Bw, N, _ = win.shape
+    qkv = F.linear(win, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"])
+    qkv = qkv.reshape(Bw, N, 3, NUM_HEADS, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = sd[pre + "attn.relative_position_bias_table"][_rel_pos_index(ws).reshape(-1)]
+    attn = attn + bias.reshape(N, N, NUM_HEADS).permute(2, 0, 1).unsqueeze(0)
+    if shift > 0:
+        m = _shift_mask(H, W, ws, shift)
+        nW = m.shape[0]
+        attn = attn.reshape(Bw // nW, nW, NUM_HEADS, N, N) + m[None, :, None]
+        attn = attn.reshape(-1, NUM_HEADS, N, N)
+    attn = torch.softmax(attn, dim=-1)
+    o = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+    o = F.linear(o, sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"])
+    o = o.reshape(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return x + o.permute(0, 3, 1, 2)
+
+
+def attention_block(sd: SD, pre: str, x: Tensor, ws: int) -> Tensor:
+    """``Win_noShift_Attention`` (layers/layers.py:50-74); builder passes shift=ws/2."""
+    a = x
+    for i in range(3):
+        a = residual_unit(sd, f"{pre}conv_a.{i}.", a)
+    b = win_attention(sd, pre + "conv_b.0.", x, ws, ws // 2)
+    for i in (1, 2, 3):
+        b = residual_unit(sd, f"{pre}conv_b.{i}.", b)
+    b = conv_k(sd, pre + "conv_b.4.", b)
+    out = a * torch.sigmoid(b)
+    return out + x
+
+
+def g_a(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """models/builder.py:43-53."""
+    x = gdn(sd, pre + "1.", conv_k(sd, pre + "0.", x, 2), False)
+    x = gdn(sd, pre + "3.", conv_k(sd, pre + "2.", x, 2), False)
+    x = attention_block(sd, pre + "4.", x, 8)
+    x = gdn(sd, pre + "6.", conv_k(sd, pre + "5.", x, 2), False)
+    x = conv_k(sd, pre + "7.", x, 2)
+    return attention_block(sd, pre + "8.", x, 4)
+
+
+def g_s(sd: SD, pre: str, y: Tensor) -> Tensor:
+    """models/builder.py:8-18."""
+    y = attention_block(sd, pre + "0.", y, 4)
+    y = gdn(sd, pre + "2.", deconv_k(sd, pre + "1.", y), True)
+    y = gdn(sd, pre + "4.", deconv_k(sd, pre + "3.", y), True)
+    y = attention_block(sd, pre + "5.", y, 8)
+    y = gdn(sd, pre + "7.", deconv_k(sd, pre + "6.", y), True)
+    return deconv_k(sd, pre + "8.", y)
+
+
+def h_a(sd: SD, y: Tensor) -> Tensor:
+    """models/builder.py:72-82."""
+    for i, s in ((0, 1), (2, 1), (4, 2), (6, 1)):
+        y = F.gelu(conv_k(sd, f"h_a.{i}.", y, s))
+    return conv_k(sd, "h_a.8.", y, 2)
+
+
+def h_s(sd: SD, pre: str, z: Tensor) -> Tensor:
+    """models/builder.py:88-98 (subpel = conv3x3 -> PixelShuffle(2))."""
+    z = F.gelu(conv_k(sd, pre + "0.", z))
+    z = F.gelu(F.pixel_shuffle(conv_k(sd, pre + "2.0.", z), 2))
+    z = F.gelu(conv_k(sd, pre + "4.", z))
+    z = F.gelu(F.pixel_shuffle(conv_k(sd, pre + "6.0.", z), 2))
+    return conv_k(sd, pre + "8.", z)
+
+
+def cc_stack(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """models/pic.py:83-164: five conv3x3 with GELU between."""
+    for i in (0, 2, 4, 6):
+        x = F.gelu(conv_k(sd, f"{pre}{i}.", x))
+    return conv_k(sd, pre + "8.", x)
+
+
+def rem_resblock(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """layers/rem.py:37-66."""
+    o = F.leaky_relu(conv_k(sd, pre + "conv1.", x), 0.01)
+    o = F.leaky_relu(conv_k(sd, pre + "conv2.", o), 0.01)
+    idn = conv_k(sd, pre + "skip.", x) if (pre + "skip.weight") in sd else x
+    return o + idn
+
+
+def rem_block(sd: SD, pre: str, y_ck: Tensor, ep_base: Tensor, ep_prog: Tensor, att: Tensor) -> Tensor:
+    """``LatentRateReduction.forward`` (layers/rem.py:130-141)."""
+    def seq(name, t):
+        i = 0
+        while f"{pre}{name}.{i}.conv1.weight" in sd:
+            t = rem_resblock(sd, f"{pre}{name}.{i}.", t)
+            i += 1
+        return t
+    f_lat = seq("enc_base_rep", y_ck)
+    f_prog = seq("enc_progressive_entropy_params", ep_prog)
+    f_base = seq("enc_base_entropy_params", ep_base)
+    ret = seq("enc", torch.cat([f_lat, f_base, f_prog], dim=1))
+    return ep_prog + ret * att
+
+
+# --------------------------------------------------------------------------
+# model data flow  (models/pic.py:278-298, 497-666; models/rem_pic.py:142-220, 229-422)
+# --------------------------------------------------------------------------
+def compute_hyperprior(sd: SD, y: Tensor, quality: float):
+    z = h_a(sd, y)
+    z_hat, z_lik = eb_forward(sd, z)
+    if quality == 0:
+        return h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_scale_s.0.", z_hat), z_lik, z_hat
+    mean = torch.cat([h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_mean_s.1.", z_hat)], 1)
+    scl = torch.cat([h_s(sd, "h_scale_s.0.", z_hat), h_s(sd, "h_scale_s.1.", z_hat)], 1)
+    return mean, scl, z_lik, z_hat
+
+
+def find_check_quality(check_levels: Sequence[float], quality: float):
+    """models/rem_pic.py:142-165."""
+    cl = list(check_levels)
+    if quality <= cl[0]:
+        return 0, 0, -1
+    if len(cl) in (2, 3) and cl[0] < quality <= cl[1]:
+        return cl[0], cl[1], 0
+    if len(cl) == 2 and quality > cl[1]:
+        return cl[1], 10, 1
+    if len(cl) == 3 and cl[1] < quality <= cl[2]:
+        return cl[1], cl[-1], 1
+    return cl[-1], 10, -1
+
+
+def rem_index(check_levels: Sequence[float], quality: float) -> int:
+    """models/rem_pic.py:200-213."""
+    cl = list(check_levels)
+    if len(cl) == 1:
+        return 0
+    if len(cl) == 2:
+        return 0 if cl[0] < quality <= cl[1] else 1
+    if cl[0] < quality <= cl[1]:
+        return 0
+    if cl[1] < quality <= cl[2]:
+        return 1
+    return 2
+
+
+def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320, chunk: int = 32,
+                           max_support: int = 5, prog_support: int = 5,
+                           checkpoint_ref: Optional[Tensor] = None,
+                           check_levels: Optional[Sequence[float]] = None,
+                           mu_std: bool = True) -> dict:
+    """``VarianceMaskingPIC.forward_single_quality`` (models/pic.py:497-666) and, when
+    ``check_levels`` is given, ``VarianceMaskingPICREM.forward`` in eval mode
+    (models/rem_pic.py:229-422).  All flags of the README config are on
+    (multiple encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable).
+    """
+    rem = check_levels is not None
+    with torch.no_grad():
+        y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)
+        means_h, scales_h, z_lik, z_hat = compute_hyperprior(sd, y, quality)
+        ns0 = div // chunk
+        ys = y.chunk(y.shape[1] // chunk, 1)
+        yhat_b: List[Tensor] = []
+        lik: List[Tensor] = []
+        mu_b, std_b = [], []
+        for i in range(ns0):
+            sup = yhat_b[:min(max_support, i)]
+            msup = torch.cat([means_h[:, :div]] + sup, 1)
+            ssup = torch.cat([scales_h[:, :div]] + sup, 1)
+            mu = cc_stack(sd, f"cc_mean_transforms.{i}.", msup)
+            sc = cc_stack(sd, f"cc_scale_transforms.{i}.", ssup)
+            mu_b.append(mu)
+            std_b.append(sc)
+            lik.append(gaussian_likelihood(ys[i], sc, mu))
+            yh = torch.round(ys[i] - mu) + mu
+            lrp = cc_stack(sd, f"lrp_transforms.{i}.", torch.cat([msup, yh], 1))
+            yhat_b.append(yh + 0.5 * torch.tanh(lrp))
+        y_base = torch.cat(yhat_b, 1)
+        if quality == 0:
+            x_hat = g_s(sd, "g_s.0.", y_base).clamp(0, 1)
+            return {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
+                    "y_hat": y_base, "y_base": y_base, "mu_base": torch.cat(mu_b, 1),
+                    "std_base": torch.cat(std_b, 1), "z_hat": z_hat, "y": y}
+
+        ck = checkpoint_ref.chunk(10, 1) if checkpoint_ref is not None else None
+        mu_tot, std_tot, mu_p, std_p, masks, yhat_p = [], [], [], [], [], []
+        for j in range(ns0):
+            r = ys[ns0 + j] - ys[j]
+            s = min(prog_support, j)
+            msup = torch.cat([means_h[:, div:], yhat_b[j]] + mu_tot[j - s:j], 1)
+            ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + std_tot[j - s:j], 1)
+            mu = cc_stack(sd, f"cc_mean_transforms_prog.{j}.", msup)
+            sc = cc_stack(sd, f"cc_scale_transforms_prog.{j}.", ssup)
+            mu_tot.append(mu + yhat_b[j])
+            std_tot.append(sc)
+            if rem and ck is not None and quality > check_levels[0]:
+                att = variance_mask(sc, quality)                      # rem_pic.py:185-192
+                if mu_std:
+                    att = torch.cat([att, att], 1)
+                ri = rem_index(check_levels, quality)
+                ep = rem_block(sd, f"post_latent.{ri}.{j}.", ck[j],
+                               torch.cat([mu_b[j], std_b[j]], 1),
+                               torch.cat([mu, sc], 1) if mu_std else sc, att)
+                if mu_std:
+                    mu, sc = ep.chunk(2, 1)
+                else:
+                    sc = ep
+            mu_p.append(mu)
+            std_p.append(sc)
+            m = variance_mask(sc, quality)                               # pic.py:621-622
+            masks.append(m)
+            lik.append(gaussian_likelihood((r - mu) * m, sc * m, None))  # pic.py:625-628
+            rh = torch.round(r - mu) * m + mu                            # pic.py:629
+            lrp = cc_stack(sd, f"lrp_transforms_prog.{j}.", torch.cat([msup, rh], 1))
+            rh = rh + 0.5 * torch.tanh(lrp)
+            yhat_p.append(rh + yhat_b[j])
+        y_prog = torch.cat(yhat_p, 1)
+        x_hat = g_s(sd, "g_s.1.", y_prog).clamp(0, 1)
+        return {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
+                "y_hat": y_prog, "y_base": y_base, "y_prog": y_prog,
+                "mu_base": torch.cat(mu_b, 1), "mu": torch.cat(mu_p, 1),
+                "std_base": torch.cat(std_b, 1), "std": torch.cat(std_p, 1),
+                "mask": torch.cat(masks, 1), "z_hat": z_hat, "y": y}
+
+
+# --------------------------------------------------------------------------
+# A.8 metrics  (utility/functions.py:172-174, training/loss.py:217-228)
+# --------------------------------------------------------------------------
+def psnr(a: Tensor, b: Tensor) -> float:
+    mse = F.mse_loss(a, b).item()
+    return -10 * math.log10(mse)
+
+
+def bpp(likelihoods: dict, num_pixels: int) -> float:
+    """``RateLoss`` style: sum over y and z of log(lik) / (-ln2 * B*H*W)."""
+    tot = 0.0
+    for v in likelihoods.values():
+        tot += torch.log(v.double()).sum().item() / (-math.log(2) * num_pixels)
+    return tot
+
+
+def log2_sum_per_image(lik: Tensor) -> Tensor:
+    return torch.log2(lik.double()).flatten(1).sum(1)

@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+README_ARGS = dict(N=192, M=640, multiple_decoder=True, multiple_encoder=True, multiple_hyperprior=True,
+                   dim_chunk=32, division_dimension=[320, 640], mask_policy="point-based-std",
+                   support_progressive_slices=5, delta_encode=True, total_mu_rep=True, all_scalable=True)
+
+
+@pytest.fixture(scope="session")
+def readme_args():
+    import argparse
+    return argparse.Namespace(model="rem", check_levels=[0.75], mu_std=True, dimension="middle", **README_ARGS)
+
+
+@pytest.fixture(scope="session")
+def synth_model_cpu(readme_args):
+    """REM model (README config) on CPU with the deterministic synthetic weights, + its state_dict."""
+    import torch
+    import vampic
+    torch.manual_seed(0)
+    net = vampic.get_model(readme_args, "cpu").eval()
+    sd = vampic.synth.synth_state_dict(net.state_dict(), seed=0)
+    torch.nn.Module.load_state_dict(net, sd)
+    return net, sd
+
+
+@pytest.fixture(scope="session")
+def gpu_model(synth_model_cpu):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    net, sd = synth_model_cpu
+    import copy
+    g = copy.deepcopy(net).to("cuda").eval()
+    return g, sd

@@ -1,0 +1,104 @@
+"""End-to-end parity of forward_single_quality (HIP plan through the C ABI) against the CPU
+oracle on the same seeded weights and inputs.  Tolerances from BASELINE.json north_star:
+mask indices bit-identical, |dPSNR| <= 1e-4 dB, |dbpp| <= 1e-6 (relative to max(1,bpp):
+the synthetic weights give ~20 bpp, 40x a trained model's rate)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vampic                    # noqa: E402
+import vampic_oracle as O        # noqa: E402
+
+
+def _cmp(out, ref, B, H, W, q):
+    xg, xr = out["x_hat"].cpu(), ref["x_hat"]
+    assert xg.shape == xr.shape
+    x_err = (xg - xr).abs().max().item()
+    lg = {k: v.cpu() for k, v in out["likelihoods"].items()}
+    bpp_g, bpp_r = O.bpp(lg, B * H * W), O.bpp(ref["likelihoods"], B * H * W)
+    # kernel-side accumulation of log2(lik)
+    bpp_k = -out["log2_likelihood_sum"].sum().item() / (B * H * W)
+    rep = {"x_err": x_err, "bpp_gpu": bpp_g, "bpp_ref": bpp_r, "bpp_kernel": bpp_k}
+    if "mask" in ref:
+        flips = int((out["mask"].cpu() != ref["mask"]).sum().item())
+        rep["mask_flips"] = flips
+    yflip = int((torch.round(out["y_hat"].cpu() - ref["y_hat"]).abs() >= 1).sum().item())
+    rep["latent_symbol_flips"] = yflip
+    return rep
+
+
+@pytest.mark.parametrize("q", [0, 0.5, 2.5, 10])
+def test_forward_single_quality_parity(gpu_model, q):
+    net, sd = gpu_model
+    B, H, W = 2, 128, 192
+    x = vampic.synth.synth_image(B, H, W, seed=1)
+    ref = O.forward_single_quality(sd, x, q)
+    with torch.no_grad():
+        out = net.forward_single_quality(x.cuda(), q, training=False)
+    rep = _cmp(out, ref, B, H, W, q)
+    print(q, rep)
+    assert rep.get("mask_flips", 0) == 0, rep
+    assert rep["latent_symbol_flips"] == 0, rep
+    psnr_g, psnr_r = O.psnr(x, out["x_hat"].cpu()), O.psnr(x, ref["x_hat"])
+    assert abs(psnr_g - psnr_r) <= 1e-4, (psnr_g, psnr_r)
+    assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= 1e-6 * max(1.0, rep["bpp_ref"]), rep
+    assert abs(rep["bpp_kernel"] - rep["bpp_ref"]) <= 1e-6 * max(1.0, rep["bpp_ref"]), rep
+    for k in ("y_hat", "mu_base", "std_base"):
+        a, b = out[k].cpu(), ref[k]
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), k
+
+
+def test_graph_replay_equals_eager(gpu_model):
+    net, _ = gpu_model
+    x = vampic.synth.synth_image(1, 64, 64, seed=2).cuda()
+    with torch.no_grad():
+        net.use_graph = False
+        a = net.forward_single_quality(x, 2.5)
+        net.use_graph = True
+        b = net.forward_single_quality(x, 2.5)
+        c = net.forward_single_quality(x, 2.5)
+    for k in ("x_hat", "y_hat", "mask"):
+        assert torch.equal(a[k], b[k]) and torch.equal(b[k], c[k]), k      # deterministic, bit for bit
+
+
+def test_rem_forward_parity(gpu_model):
+    net, sd = gpu_model
+    B, H, W = 1, 64, 128
+    x = vampic.synth.synth_image(B, H, W, seed=3)
+    base = O.forward_single_quality(sd, x, 0.75, check_levels=[0.75])
+    ck = base["y_hat"]
+    ref = O.forward_single_quality(sd, x, 2.5, check_levels=[0.75], checkpoint_ref=ck)
+    with torch.no_grad():
+        ck_g = net.ExtractChekpointRepr(x.cuda(), 0.75)
+        out = net.forward_single_quality(x.cuda(), 2.5, training=False, checkpoint_ref=ck)
+    assert (ck_g.cpu() - ck).abs().max().item() <= 2e-4 * ck.abs().max().item()
+    rep = _cmp(out, ref, B, H, W, 2.5)
+    print("rem", rep)
+    assert rep["mask_flips"] == 0 and rep["latent_symbol_flips"] == 0, rep
+    assert abs(O.psnr(x, out["x_hat"].cpu()) - O.psnr(x, ref["x_hat"])) <= 1e-4
+    assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= 1e-6 * max(1.0, rep["bpp_ref"]), rep
+
+
+def test_module_surface_of_the_harness(gpu_model):
+    """demo.py / test/*.py reach into the model for sub-modules."""
+    net, sd = gpu_model
+    x = vampic.synth.synth_image(1, 64, 64, seed=4)
+    with torch.no_grad():
+        y0 = net.g_a[0](x.cuda())
+        ref = O.g_a(sd, "g_a.0.", x)
+        assert (y0.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        y = torch.cat([y0, net.g_a[1](x.cuda())], 1)
+        means, scales, zl = net.compute_hyperprior(y, quality=2.5)
+        assert means.shape == (1, 640, 4, 4) and scales.shape == (1, 640, 4, 4) and zl.shape == (1, 192, 1, 1)
+        t = torch.randn(1, 320, 4, 4, device="cuda")
+        mu = net.cc_mean_transforms[0](t)
+        ref_mu = O.cc_stack(sd, "cc_mean_transforms.0.", t.cpu())
+        assert (mu.cpu() - ref_mu).abs().max().item() <= 1e-4 * max(1.0, ref_mu.abs().max().item())
+        xh = net.g_s[1](torch.randn(1, 320, 4, 4, device="cuda"))
+        assert xh.shape == (1, 3, 64, 64)
+    for name in ("ns0", "ns1", "num_slices", "max_support_slices", "division_dimension", "division_channel",
+                 "multiple_encoder", "multiple_decoder", "multiple_hyperprior", "delta_encode", "total_mu_rep",
+                 "mu_std", "check_levels", "num_rems", "enable_rem"):
+        assert hasattr(net, name), name

@@ -1,0 +1,199 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle /
+plain fp32 ATen CPU ops on the same seeded inputs.  Integer/rank work is bit-exact;
+float work is compared with the tolerance written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import vampic                                     # noqa: E402
+from vampic import layers as Ly, ops, _lib as L  # noqa: E402
+import vampic_oracle as O                         # noqa: E402
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _close(a, b, rtol=2e-5, atol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{what}: max abs err {err:.3e} vs ref magnitude {ref:.3e}"
+
+
+def _fill(m, seed):
+    sd = vampic.synth.synth_state_dict(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    return {k: v.clone() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("cin,cout,k,s,hw", [(32, 32, 3, 1, (16, 16)), (352, 224, 3, 1, (16, 24)), (176, 128, 3, 1, (9, 7)),
+                                              (192, 192, 5, 2, (32, 32)), (3, 192, 5, 2, (64, 96)), (96, 192, 1, 1, (16, 16)),
+                                              (288, 256, 3, 2, (16, 16)), (192, 320, 5, 2, (32, 32))])
+def test_conv2d(cin, cout, k, s, hw):
+    m = Ly.Conv2d(cin, cout, k, s)
+    sd = _fill(m, 1)
+    x = _rand((2, cin) + hw, 2)
+    ref = F.conv2d(x, sd["weight"], sd["bias"], stride=s, padding=k // 2)
+    with torch.no_grad():
+        out = m.cuda()(x.cuda())
+    assert out.shape == ref.shape
+    _close(out, ref, what=f"conv {cin}->{cout} k{k} s{s}")
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(320, 192, (4, 4)), (192, 192, (8, 12)), (192, 3, (16, 16))])
+def test_deconv(cin, cout, hw):
+    m = Ly.ConvTranspose2d(cin, cout)
+    sd = _fill(m, 3)
+    x = _rand((2, cin) + hw, 4)
+    ref = F.conv_transpose2d(x, sd["weight"], sd["bias"], stride=2, padding=2, output_padding=1)
+    with torch.no_grad():
+        out = m.cuda()(x.cuda())
+    _close(out, ref, what=f"deconv {cin}->{cout}")
+
+
+def test_subpel_and_stack():
+    m = vampic.models._hyper_synthesis(192, 192, 320)
+    sd = _fill(m, 5)
+    x = _rand((2, 192, 2, 3), 6)
+    ref = O.h_s({("p." + k): v for k, v in sd.items()}, "p.", x)
+    with torch.no_grad():
+        out = m.cuda()(x.cuda())
+    _close(out, ref, what="hyper synthesis stack")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn(inverse):
+    m = Ly.GDN(192, inverse=inverse)
+    sd = _fill(m, 7)
+    x = _rand((2, 192, 8, 8), 8, 2.0)
+    ref = O.gdn({("g." + k): v for k, v in sd.items()}, "g.", x, inverse)
+    with torch.no_grad():
+        out = m.cuda()(x.cuda())
+    _close(out, ref, what="gdn")
+
+
+@pytest.mark.parametrize("dim,ws,hw", [(192, 8, (16, 24)), (320, 4, (8, 8))])
+def test_attention_block(dim, ws, hw):
+    m = Ly.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=ws // 2)
+    sd = _fill(m, 9)
+    x = _rand((2, dim) + hw, 10)
+    ref = O.attention_block({("a." + k): v for k, v in sd.items()}, "a.", x, ws)
+    with torch.no_grad():
+        out = m.cuda()(x.cuda())
+    _close(out, ref, rtol=5e-5, atol=5e-5, what="attention block")
+
+
+def test_rem_block():
+    m = Ly.LatentRateReduction(32, True, "middle")
+    sd = _fill(m, 11)
+    yck, epb, epp = _rand((2, 32, 8, 8), 12, 3.0), _rand((2, 64, 8, 8), 13), _rand((2, 64, 8, 8), 14)
+    att = (torch.rand((2, 32, 8, 8), generator=torch.Generator().manual_seed(15)) > 0.5).float()
+    att2 = torch.cat([att, att], 1)
+    ref = O.rem_block({("r." + k): v for k, v in sd.items()}, "r.", yck, epb, epp, att2)
+    with torch.no_grad():
+        out = m.cuda()(yck.cuda(), epb.cuda(), epp.cuda(), att2.cuda())
+    _close(out, ref, what="REM block")
+
+
+# ---------------------------------------------------------------- variance mask: bit-exact
+Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 16, 16), (2, 32, 32, 48), (2, 32, 5, 3), (1, 4, 1, 1)])
+def test_variance_mask_bit_exact(shape):
+    B, C, h, w = shape
+    s = vampic.synth.synth_sigma(B, C * h * w, seed=3).reshape(B, C, h, w)
+    cm = Ly.ChannelMask("point-based-std")
+    for q in Q_LEVS:
+        ref = O.variance_mask_np(s.numpy(), q)
+        out = cm(s.cuda(), pr=q).cpu().numpy()
+        assert out.shape == ref.shape
+        assert np.array_equal(out, ref), f"mask XOR = {(out != ref).sum()} at q={q} shape={shape}"
+
+
+def test_variance_mask_edge_cases():
+    cm = Ly.ChannelMask("point-based-std")
+    # all-equal segment: ties are all kept
+    s = torch.full((1, 32, 4, 4), 1.25)
+    assert cm(s.cuda(), pr=5).sum().item() == s.numel()
+    # NaN in a segment -> threshold NaN -> all zero, other segments unaffected
+    s = vampic.synth.synth_sigma(2, 32 * 16, seed=5).reshape(2, 32, 4, 4)
+    s[0, 3, 1, 1] = float("nan")
+    out = cm(s.cuda(), pr=3).cpu().numpy()
+    ref = O.variance_mask_np(s.numpy(), 3)
+    assert out[0].sum() == 0 and np.array_equal(out, ref)
+    # +-0 and denormals and infinities
+    s = torch.tensor([0.0, -0.0, 1e-42, -1e-42, float("inf"), -float("inf"), 3.0, 2.0] * 4).reshape(1, 4, 2, 4)
+    for q in (1, 2.5, 5, 9):
+        assert np.array_equal(cm(s.cuda(), pr=q).cpu().numpy(), O.variance_mask_np(s.numpy(), q))
+    # nestedness in q
+    s = vampic.synth.synth_sigma(1, 8192, seed=9).reshape(1, 32, 16, 16).cuda()
+    prev = None
+    for q in (0.5, 1, 2.5, 5, 7.5):
+        mk = cm(s, pr=q)
+        if prev is not None:
+            assert bool((mk >= prev).all())
+        prev = mk
+    # two-levels policy and unknown policy
+    assert cm(s, pr=0, mask_pol="two-levels").sum().item() == 0
+    assert cm(s, pr=2, mask_pol="two-levels").mean().item() == 1
+    with pytest.raises(NotImplementedError):
+        cm(s, pr=2, mask_pol="nope")
+
+
+def test_prog_mask_matches_oracle():
+    cm = Ly.ChannelMask("point-based-std")
+    blocks = [vampic.synth.synth_sigma(1, 32 * 64, seed=20 + i).reshape(1, 32, 8, 8) for i in range(10)]
+    for q in (0, 0.5, 2.5, 10):
+        ref = O.prog_mask_np([b.numpy() for b in blocks], q)
+        out = cm.ProgMask([b.cuda() for b in blocks], q).cpu().numpy()
+        assert np.array_equal(out, ref)
+
+
+# ---------------------------------------------------------------- Gaussian conditional
+def test_gauss_likelihood_and_indexes():
+    gc = vampic.GaussianConditional(None).cuda()
+    y, mu = _rand((2, 32, 16, 16), 30, 6.0), _rand((2, 32, 16, 16), 31, 4.0)
+    sg = vampic.synth.synth_sigma(2, 32 * 256, seed=32).reshape(2, 32, 16, 16)
+    out, lik = gc(y.cuda(), sg.cuda(), mu.cuda(), training=False)
+    ref_out = torch.round(y - mu) + mu
+    assert torch.equal(out.cpu(), ref_out), "quantised latent must be bit-exact"
+    ref = O.gaussian_likelihood(y, sg, mu)
+    rel = ((lik.cpu() - ref).abs() / ref).max().item()
+    assert rel < 2e-5, f"likelihood rel err {rel}"          # erfc implementations differ by a few ulp
+    out2, lik2 = gc(y.cuda(), sg.cuda(), None, training=False)
+    assert torch.equal(out2.cpu(), torch.round(y))
+    assert ((lik2.cpu() - O.gaussian_likelihood(y, sg, None)).abs() / O.gaussian_likelihood(y, sg, None)).max() < 2e-5
+    gc.update_scale_table([float(v) for v in O.scale_table()])
+    idx = gc.build_indexes(sg.cuda())
+    assert torch.equal(idx.cpu(), O.build_indexes(sg)), "build_indexes must be bit-exact"
+    sym = gc.quantize(y.cuda(), "symbols", mu.cuda())
+    assert torch.equal(sym.cpu(), torch.round(y - mu).int())
+
+
+def test_entropy_bottleneck():
+    eb = vampic.EntropyBottleneck(192)
+    sd = _fill(eb, 40)
+    z = _rand((2, 192, 4, 6), 41, 5.0)
+    zh_ref, lik_ref = O.eb_forward({("e." + k): v for k, v in sd.items()}, z, "e.")
+    zh, lik = eb.cuda()(z.cuda(), training=False)
+    assert torch.equal(zh.cpu(), zh_ref), "z_hat must be bit-exact"
+    rel = ((lik.cpu() - lik_ref).abs() / lik_ref).max().item()
+    assert rel < 1e-4, f"EB likelihood rel err {rel}"
+
+
+def test_errors_are_loud():
+    m = Ly.Conv2d(8, 8, 3)
+    x = torch.randn(1, 8, 4, 4, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        m.cuda()(x)                                  # no silent autograd fallback
+    with pytest.raises(Exception):
+        ops.conv_problem(m.cuda().packed(), [ops.from_nchw(torch.randn(1, 4, 4, 4, device="cuda"))],
+                         ops.new_view(1, 4, 4, 8))   # channel mismatch
