@@ -386,6 +386,7 @@ class _FsqPlan:
         self.base_only, self.rem_idx = base_only, rem_idx
         self.pr = 0.0
         self.graphs: Dict[float, ops.Graph] = {}
+        self.stream = None
         plan = self.plan = E.Plan(device)
         h, w = H // 16, W // 16
         d = m.division_dimension[0]
@@ -493,24 +494,32 @@ class _FsqPlan:
 
     # -------------------------------------------------------------------------------------------
     def execute(self, x, pr, checkpoint_ref, use_graph, clone):
+        """Run the plan on the model's own HIP stream (hipGraph capture is not allowed on the
+        legacy default stream), ordered after / before the caller's current stream."""
         self.pr = float(pr)
-        self.x_in.copy_(x)
-        if checkpoint_ref is not None:
-            ck = ops.from_nchw(checkpoint_ref)
-            self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])
-        if use_graph:
-            g = self.graphs.get(self.pr)
-            if g is None:
-                self.plan.run()                      # warm-up: every code object loaded before capture
-                torch.cuda.current_stream().synchronize()
-                g = ops.Graph()
-                g.capture(self.plan.run)
-                if len(self.graphs) > 32:
-                    self.graphs.clear()
-                self.graphs[self.pr] = g
-            g.launch()
-        else:
-            self.plan.run()
+        cur = torch.cuda.current_stream(self.x_in.device)
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.x_in.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x)
+            if checkpoint_ref is not None:
+                ck = ops.from_nchw(checkpoint_ref.to(self.x_in.device))
+                self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])
+            if use_graph:
+                g = self.graphs.get(self.pr)
+                if g is None:
+                    self.plan.run()                      # warm-up: every code object loaded before capture
+                    self.stream.synchronize()
+                    g = ops.Graph()
+                    g.capture(self.plan.run)
+                    if len(self.graphs) > 32:
+                        self.graphs.clear()
+                    self.graphs[self.pr] = g
+                g.launch()
+            else:
+                self.plan.run()
+        cur.wait_stream(self.stream)
         fin = (lambda t: t.clone()) if clone else (lambda t: t)
         nchw = lambda v: fin(v.torch_nchw())
         out = {"x_hat": fin(self.x_hat),

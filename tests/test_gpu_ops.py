@@ -59,7 +59,8 @@ def test_deconv(cin, cout, hw):
 
 
 def test_subpel_and_stack():
-    m = vampic.models._hyper_synthesis(192, 192, 320)
+    from vampic.models import _hyper_synthesis
+    m = _hyper_synthesis(192, 192, 320)
     sd = _fill(m, 5)
     x = _rand((2, 192, 2, 3), 6)
     ref = O.h_s({("p." + k): v for k, v in sd.items()}, "p.", x)
@@ -166,11 +167,13 @@ def test_gauss_likelihood_and_indexes():
     ref_out = torch.round(y - mu) + mu
     assert torch.equal(out.cpu(), ref_out), "quantised latent must be bit-exact"
     ref = O.gaussian_likelihood(y, sg, mu)
-    rel = ((lik.cpu() - ref).abs() / ref).max().item()
-    assert rel < 2e-5, f"likelihood rel err {rel}"          # erfc implementations differ by a few ulp
+    # lik = Phi(a) - Phi(b): two erfc values of magnitude <= 1 whose implementations differ by a
+    # few ulp (6e-8 each), so the tolerance is absolute
+    err = (lik.cpu() - ref).abs().max().item()
+    assert err < 3e-7, f"likelihood abs err {err}"
     out2, lik2 = gc(y.cuda(), sg.cuda(), None, training=False)
     assert torch.equal(out2.cpu(), torch.round(y))
-    assert ((lik2.cpu() - O.gaussian_likelihood(y, sg, None)).abs() / O.gaussian_likelihood(y, sg, None)).max() < 2e-5
+    assert (lik2.cpu() - O.gaussian_likelihood(y, sg, None)).abs().max() < 3e-7
     gc.update_scale_table([float(v) for v in O.scale_table()])
     idx = gc.build_indexes(sg.cuda())
     assert torch.equal(idx.cpu(), O.build_indexes(sg)), "build_indexes must be bit-exact"
