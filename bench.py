@@ -46,7 +46,8 @@ def cpu_baseline(sd, H, W, quality, budget_s=20.0):
     """Oracle (kind="port") on the host cores: as many 256x256 images as fit ~budget_s."""
     import vampic
     import vampic_oracle as O
-    cores = torch.get_num_threads()
+    cores = int(os.environ.get("VAMPIC_CPU_THREADS", "16"))   # one-GPU box CPU share
+    torch.set_num_threads(cores)
     x1 = vampic.synth.synth_image(1, H, W, seed=7)
     t0 = time.perf_counter()
     O.forward_single_quality(sd, x1, quality)                      # warm-up + calibration
