@@ -114,12 +114,10 @@ def main():
             out = net.forward_single_quality(x, q, clone=False)
         sync_all()
         dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    from vampic import sharding
+    dt = sharding.max_over_ranks(dt, dev)                     # slowest rank (RCCL all-reduce MAX)
     ms_step = dt / a.steps * 1e3
-    mp_s = world * B * H * W * a.steps / 1e6 / dt
+    mp_s = sharding.whole_job_megapixels_per_s(B, H, W, a.steps, world, dt)
 
     # ---- roofline of the dominant kernel, measured live with HIP events (eager replay, same plan)
     roof = None

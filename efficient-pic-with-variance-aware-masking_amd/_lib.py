@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vam_last_error": (C.c_char_p, []),
     "vam_version": (C.c_int, []),
     "vam_device_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "vam_conv_struct_size": (C.c_size_t, []),
     "vam_conv_wpack_floats": (C.c_size_t, [C.c_int] * 4),
     "vam_pack_conv_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_pack_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -110,6 +111,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.vam_conv_struct_size() != C.sizeof(VamConv):
+        raise VamError(f"ABI mismatch: sizeof(vam_conv) is {lib.vam_conv_struct_size()} in libvampic.so, {C.sizeof(VamConv)} in the binding")
     _lib = lib
     return lib
 

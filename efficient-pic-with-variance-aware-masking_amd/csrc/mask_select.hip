@@ -161,7 +161,11 @@ __global__ __launch_bounds__(1024) void variance_mask_kernel(const MaskArgs a) {
   const float d = hi_v - lo_v;
   float thr = (a.w < 0.5f) ? __builtin_fmaf(a.w, d, lo_v) : __builtin_fmaf(a.w - 1.0f, d, hi_v);
   if (sh_nan) thr = __uint_as_float(0x7FC00000u);
+#ifdef VAM_MASK_DEBUG
+  if (tid == 0 && a.thr) { a.thr[seg * 4] = thr; a.thr[seg * 4 + 1] = lo_v; a.thr[seg * 4 + 2] = hi_v; a.thr[seg * 4 + 3] = a.w; }
+#else
   if (tid == 0 && a.thr) a.thr[seg] = thr;
+#endif
 
   if (MAXV > 0) {
 #pragma unroll
@@ -208,8 +212,12 @@ extern "C" int vam_variance_mask(const float* sigma, int ld, long batch_stride, 
   else {
     a.mode = 0;
     const double q_keep = pr * 0.1;            // python float arithmetic of :138-139
-    const float qt = (float)(1.0 - q_keep);    // scalar_tensor(q, float32)
-    const float rank = qt * (float)(n - 1);    // fp32 multiply (q * last_index)
+    // volatile: each step must round to fp32 exactly like ATen's tensor ops; a host-side
+    // contraction of (qt*(n-1)) - lo into one fma changes w in the 5th digit and the
+    // threshold by an ulp (caught by tests/golden thresholds).
+    volatile float qt = (float)(1.0 - q_keep);       // scalar_tensor(q, float32)
+    volatile float last = (float)(n - 1);
+    volatile float rank = qt * last;                 // fp32 multiply (q * last_index)
     const float lo = floorf(rank);
     a.k_lo = (int)lo;
     a.k_hi = (int)ceilf(rank);

@@ -72,6 +72,7 @@ extern "C" {
 
 const char* vam_last_error(void) { return g_err; }
 int vam_version(void) { return 100; }
+size_t vam_conv_struct_size(void) { return sizeof(vam_conv); }
 
 int vam_device_info(char* name128, int* cu_count) {
   int n = 0;

@@ -34,6 +34,7 @@ class Plan:
         self.keep: List[object] = []          # buffers / ctypes arrays referenced by the steps
         self._graph: Optional[ops.Graph] = None
         self.flops = 0.0
+        self.meta: List[dict] = []            # one entry per step: what it is and its algorithmic FLOP
 
     # ---- buffers
     def buf(self, B, H, W, C, zero=False) -> View:
@@ -49,13 +50,34 @@ class Plan:
             arr = (L.VamConv * len(chunk))(*chunk)
             n = len(chunk)
             self.keep.append(arr)
+            fl = 0.0
             for c in chunk:
                 cin = sum(c.seg[k].C for k in range(c.n_seg))
-                self.flops += 2.0 * c.B * c.Ho * c.Wo * c.N * cin * c.kh * c.kw
+                fl += 2.0 * c.B * c.Ho * c.Wo * c.N * cin * c.kh * c.kw
+            self.flops += fl
+            c0 = chunk[0]
+            self.meta.append({"kind": "conv", "flops": fl, "desc": f"{n}x[{sum(c0.seg[k].C for k in range(c0.n_seg))}->{c0.N} "
+                              f"k{c0.kh}x{c0.kw} s{c0.stride} P={c0.B * c0.Ho * c0.Wo}]"})
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
-    def call(self, fn: Callable[[], None]):
+    def call(self, fn: Callable[[], None], desc: str = "op"):
+        self.meta.append({"kind": "op", "flops": 0.0, "desc": desc})
         self.steps.append(fn)
+
+    def profile(self, reps: int = 3):
+        """Per-step time (ms, best of reps) measured with events on the current stream."""
+        best = [float("inf")] * len(self.steps)
+        for _ in range(reps):
+            evs = []
+            for s in self.steps:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                s()
+                b.record()
+                evs.append((a, b))
+            torch.cuda.current_stream().synchronize()
+            best = [min(t, a.elapsed_time(b)) for t, (a, b) in zip(best, evs)]
+        return [dict(m, ms=t) for m, t in zip(self.meta, best)]
 
     # ---- execution
     def run(self):

@@ -41,6 +41,20 @@ def _gen(name: str, seed: int) -> torch.Generator:
     return g
 
 
+def _uniform(shape, g: torch.Generator) -> torch.Tensor:
+    """U[0,1) on a 2^-24 grid built from integer draws: int -> float conversion and the
+    scaling are exact, so the value is bit-identical on every host (unlike torch.randn /
+    torch.exp, whose vectorised CPU kernels differ by an ulp between AVX2 and AVX-512)."""
+    return torch.randint(0, 1 << 24, shape, generator=g, dtype=torch.int32).to(torch.float32) * (2.0 ** -24)
+
+
+def _normal(shape, g: torch.Generator) -> torch.Tensor:
+    """Unit-variance bell (Irwin-Hall of 4 uniforms), exact IEEE adds only."""
+    u = _uniform(shape, g) + _uniform(shape, g)
+    v = _uniform(shape, g) + _uniform(shape, g)
+    return ((u + v) - 2.0) * 1.7320508075688772
+
+
 def synth_tensor(name: str, like: torch.Tensor, seed: int = 0):
     """Return the synthetic value for state_dict entry ``name`` (or None to keep
     the module's own default, for derived buffers)."""
@@ -48,12 +62,12 @@ def synth_tensor(name: str, like: torch.Tensor, seed: int = 0):
         return None
     shape = tuple(like.shape)
     g = _gen(name, seed)
-    rn = lambda: torch.randn(shape, generator=g, dtype=torch.float32)
-    ru = lambda: torch.rand(shape, generator=g, dtype=torch.float32)
+    rn = lambda: _normal(shape, g)
+    ru = lambda: _uniform(shape, g)
     leaf = name.rsplit(".", 1)[-1]
     ped = (2.0 ** -18) ** 2
     if leaf == "beta":
-        return torch.sqrt(0.8 + 0.4 * ru() + ped)
+        return torch.sqrt(0.8 + 0.4 * ru() + ped)      # sqrt is correctly rounded everywhere
     if leaf == "gamma":
         c = shape[0]
         return torch.sqrt(0.1 * torch.eye(c) + 0.004 * ru() + ped)
@@ -100,6 +114,15 @@ def synth_tensor(name: str, like: torch.Tensor, seed: int = 0):
     return 0.1 * rn()
 
 
+def normal(shape, seed: int, scale: float = 1.0) -> torch.Tensor:
+    """Host-independent test tensor: unit-variance bell times ``scale``."""
+    return _normal(tuple(shape), _gen("normal:" + "x".join(map(str, shape)), seed)) * scale
+
+
+def uniform(shape, seed: int) -> torch.Tensor:
+    return _uniform(tuple(shape), _gen("uniform:" + "x".join(map(str, shape)), seed))
+
+
 def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
     """Fill every entry of ``template`` (name -> tensor giving shape/dtype)."""
     out = {}
@@ -113,17 +136,19 @@ def synth_image(batch: int, height: int, width: int, seed: int = 0) -> torch.Ten
     """x ~ U[0,1) fp32 NCHW, smooth-ish (low-pass of noise + noise) so that the
     synthesis transform sees image-like statistics."""
     g = _gen(f"image:{batch}x{height}x{width}", seed)
-    return torch.rand((batch, 3, height, width), generator=g, dtype=torch.float32)
+    return _uniform((batch, 3, height, width), g)
 
 
 def synth_sigma(n_seg: int, n: int, seed: int = 0) -> torch.Tensor:
-    """Operator-level scale inputs for the mask kernel: log-uniform in
-    [0.05, 300] with ~1 % exact ties and ~0.1 % negatives."""
+    """Operator-level scale inputs for the mask kernel: log-uniform-like over
+    [2^-5, 2^9) (exponent uniform, mantissa uniform — assembled from integer bits, so
+    bit-identical on every host) with ~1 % exact ties and ~0.1 % negatives."""
     g = _gen(f"sigma:{n_seg}x{n}", seed)
-    u = torch.rand((n_seg, n), generator=g)
-    s = torch.exp(math.log(0.05) + u * (math.log(300.0) - math.log(0.05)))
-    tie = torch.rand((n_seg, n), generator=g) < 0.01
+    expo = torch.randint(122, 136, (n_seg, n), generator=g, dtype=torch.int32)       # 2^-5 .. 2^8
+    mant = torch.randint(0, 1 << 23, (n_seg, n), generator=g, dtype=torch.int32)
+    s = ((expo << 23) | mant).view(torch.float32)
+    tie = torch.randint(0, 100, (n_seg, n), generator=g) == 0
     src = torch.randint(0, n, (n_seg, n), generator=g)
     s = torch.where(tie, torch.gather(s, 1, src), s)
-    neg = torch.rand((n_seg, n), generator=g) < 0.001
-    return torch.where(neg, -s, s).float().contiguous()
+    neg = torch.randint(0, 1000, (n_seg, n), generator=g) == 0
+    return torch.where(neg, -s, s).contiguous()

@@ -101,6 +101,8 @@ typedef struct vam_conv {
   vam_aux pre, mul, post, post2;
 } vam_conv;
 
+/* sizeof(vam_conv) as compiled into the library (binding layout guard). */
+size_t vam_conv_struct_size(void);
 /* Size in floats of the packed weight buffer for (kh,kw,Cin,N). */
 size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n);
 

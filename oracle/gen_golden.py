@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Imports the reference's own Python sources from
+/root/reference/src (read-only) with the two third-party stand-ins of oracle/ref_stubs
+(compressai, timm — absent offline), fills it with the deterministic synthetic weights
+of vampic.synth and stores the reference's outputs as small data files.  Nothing of the
+reference's code is copied; only inputs (re-generated from seeds) and expected outputs
+are committed.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz / *.json
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+sys.path[:0] = [os.path.join(ROOT, "oracle", "ref_stubs"), REF, ROOT]
+sys.dont_write_bytecode = True
+
+import vampic.synth as synth  # noqa: E402  (pure python/torch, no GPU needed)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def fill(module, seed):
+    sd = synth.synth_state_dict(module.state_dict(), seed)
+    torch.nn.Module.load_state_dict(module, sd)
+    return sd
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    from models import get_model                       # the reference
+    import layers as RL
+    from entropy_models import GaussianConditional, EntropyBottleneck
+
+    args = argparse.Namespace(model="rem", N=192, M=640, multiple_decoder=True, multiple_encoder=True,
+                              multiple_hyperprior=True, dim_chunk=32, division_dimension=[320, 640],
+                              mask_policy="point-based-std", support_progressive_slices=5, delta_encode=True,
+                              total_mu_rep=True, all_scalable=True, check_levels=[0.75], mu_std=True,
+                              dimension="middle")
+    net = quiet(get_model, args, "cpu").eval()
+
+    # 1. state_dict manifest
+    man = {k: [list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()}
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump({"n_params": sum(p.numel() for p in net.parameters()), "entries": man}, f)
+
+    # 2. variance mask (reference ChannelMask on operator-level sigma inputs)
+    cm = RL.ChannelMask("point-based-std")
+    rec = {}
+    for name, (B, C, h, w), seed in (("s8192", (3, 32, 16, 16), 3), ("s49152", (2, 32, 32, 48), 4), ("s480", (2, 32, 5, 3), 5)):
+        s = synth.synth_sigma(B, C * h * w, seed=seed).reshape(B, C, h, w)
+        for q in Q_LEVS:
+            m = cm(s, pr=q).numpy().astype(np.uint8)
+            rec[f"{name}_q{q}"] = np.packbits(m.reshape(-1))
+            if 0 < q < 10:
+                rec[f"{name}_q{q}_thr"] = np.array([torch.quantile(s[b].ravel(), 1.0 - q * 0.1).item() for b in range(B)],
+                                                   dtype=np.float32)
+    blocks = [synth.synth_sigma(1, 32 * 64, seed=20 + i).reshape(1, 32, 8, 8) for i in range(10)]
+    for q in (0, 0.5, 2.5, 10):
+        rec[f"prog_q{q}"] = np.packbits(cm.ProgMask(blocks, q).numpy().astype(np.uint8).reshape(-1))
+    np.savez_compressed(os.path.join(GOLD, "variance_mask.npz"), **rec)
+
+    # 3. Gaussian conditional / entropy bottleneck (operator level)
+    g = lambda shape, seed, sc=1.0: synth.normal(shape, seed, sc)
+    gc = GaussianConditional(None)
+    y, mu = g((2, 32, 16, 16), 30, 6.0), g((2, 32, 16, 16), 31, 4.0)
+    sg = synth.synth_sigma(2, 32 * 256, seed=32).reshape(2, 32, 16, 16)
+    out, lik = gc(y, sg, mu, training=False)
+    out2, lik2 = gc(y, sg, None, training=False)
+    gc.scale_table = torch.exp(torch.linspace(np.log(0.11), np.log(256), 64))
+    idx = gc.build_indexes(sg)
+    eb = EntropyBottleneck(192)
+    fill(eb, 40)
+    z = g((2, 192, 4, 6), 41, 5.0)
+    zh, zl = eb(z, training=False)
+    np.savez_compressed(os.path.join(GOLD, "entropy_ops.npz"), gc_out=out.numpy(), gc_lik=lik.numpy(),
+                        gc_out_nomean=out2.numpy(), gc_lik_nomean=lik2.numpy(), gc_idx=idx.numpy().astype(np.int8),
+                        eb_zhat=zh.detach().numpy(), eb_lik=zl.detach().numpy())
+
+    # 4. layer-level vectors
+    rec = {}
+    with torch.no_grad():
+        for inv in (False, True):
+            m = RL.GDN(192, inverse=inv)
+            fill(m, 7)
+            rec[f"gdn_inv{int(inv)}"] = m(g((2, 192, 8, 8), 8, 2.0)).numpy()
+        for dim, ws, hw in ((192, 8, (16, 24)), (320, 4, (8, 8))):
+            m = RL.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=ws // 2)
+            fill(m, 9)
+            rec[f"attn_{dim}"] = m(g((2, dim) + hw, 10)).numpy()
+        m = RL.LatentRateReduction(32, True, "middle")
+        fill(m, 11)
+        att = (synth.uniform((2, 32, 8, 8), 15) > 0.5).float()
+        rec["rem"] = m(g((2, 32, 8, 8), 12, 3.0), g((2, 64, 8, 8), 13), g((2, 64, 8, 8), 14), torch.cat([att, att], 1)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "layer_ops.npz"), **rec)
+
+    # 5. end-to-end forward_single_quality of the reference model (64x64 images: tiny tensors)
+    sd = fill(net, 0)
+    rec = {}
+    scal = {}
+    with torch.no_grad():
+        for seed in (0, 1):
+            x = synth.synth_image(1, 64, 64, seed=seed)
+            for q in (0, 0.5, 2.5, 10):
+                o = net.forward_single_quality(x, quality=q, training=False)
+                tag = f"s{seed}_q{q}"
+                rec[tag + "_x_hat"] = o["x_hat"].numpy()
+                rec[tag + "_y_hat"] = o["y_hat"].numpy()
+                rec[tag + "_lik_y"] = o["likelihoods"]["y"].numpy()
+                rec[tag + "_lik_z"] = o["likelihoods"]["z"].numpy()
+                mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
+                bits = sum(torch.log(v.double()).sum().item() for v in o["likelihoods"].values()) / (-np.log(2) * 64 * 64)
+                scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
+        # REM: checkpoint latent at q=0.75, refined pass at q=2.5
+        x = synth.synth_image(1, 64, 128, seed=0)
+        ck = net.forward_single_quality(x, quality=0.75, training=False)["y_hat"]
+        o = net.forward_single_quality(x, quality=2.5, training=False, checkpoint_ref=ck.clone())
+        rec["rem_ck"] = ck.numpy()
+        rec["rem_x_hat"] = o["x_hat"].numpy()
+        rec["rem_y_hat"] = o["y_hat"].numpy()
+        rec["rem_lik_y"] = o["likelihoods"]["y"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "forward_single_quality.npz"), **rec)
+    with open(os.path.join(GOLD, "forward_single_quality.json"), "w") as f:
+        json.dump(scal, f, indent=1)
+    print("golden vectors written to", GOLD)
+    for fn in sorted(os.listdir(GOLD)):
+        print(f"  {fn}: {os.path.getsize(os.path.join(GOLD, fn)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

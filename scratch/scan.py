@@ -7,7 +7,7 @@ sd = vampic.synth.synth_state_dict(net.state_dict(), 0); net.load_state_dict(sd)
 for (B,H,W) in [(1,64,64),(1,64,128),(1,128,128)]:
   for seed in range(4):
     x = vampic.synth.synth_image(B,H,W,seed)
-    for q in (0, 0.5, 2.5):
+    for q in (0, 0.5, 2.5, 10):
         ref = O.forward_single_quality(sd, x, q)
         with torch.no_grad(): out = net.forward_single_quality(x.cuda(), q)
         fl = int((torch.round(out["y_hat"].cpu()-ref["y_hat"]).abs()>=1).sum())

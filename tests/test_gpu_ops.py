@@ -16,8 +16,7 @@ import vampic_oracle as O                         # noqa: E402
 
 
 def _rand(shape, seed, scale=1.0):
-    g = torch.Generator().manual_seed(seed)
-    return torch.randn(shape, generator=g) * scale
+    return vampic.synth.normal(shape, seed, scale)
 
 
 def _close(a, b, rtol=2e-5, atol=2e-5, what=""):
@@ -95,7 +94,7 @@ def test_rem_block():
     m = Ly.LatentRateReduction(32, True, "middle")
     sd = _fill(m, 11)
     yck, epb, epp = _rand((2, 32, 8, 8), 12, 3.0), _rand((2, 64, 8, 8), 13), _rand((2, 64, 8, 8), 14)
-    att = (torch.rand((2, 32, 8, 8), generator=torch.Generator().manual_seed(15)) > 0.5).float()
+    att = (vampic.synth.uniform((2, 32, 8, 8), 15) > 0.5).float()
     att2 = torch.cat([att, att], 1)
     ref = O.rem_block({("r." + k): v for k, v in sd.items()}, "r.", yck, epb, epp, att2)
     with torch.no_grad():

@@ -1,0 +1,113 @@
+"""Pin the CPU oracle to the reference: the vectors under tests/golden were produced by running the
+reference's own code (oracle/gen_golden.py); the oracle must reproduce them.  Rank/index work
+is compared bit-exactly, float tensors with 1e-5 relative slack so that a different host CPU
+(another MKLDNN code path) cannot fail the suite."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vampic.synth as synth
+import vampic_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
+
+
+def _close(a, b, rtol=1e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape
+    assert (a - b).abs().max().item() <= rtol * max(1.0, b.abs().max().item())
+
+
+def _g(shape, seed, sc=1.0):
+    return synth.normal(shape, seed, sc)
+
+
+def test_variance_mask_matches_reference_bits():
+    gold = np.load(os.path.join(GOLD, "variance_mask.npz"))
+    for name, (B, C, h, w), seed in (("s8192", (3, 32, 16, 16), 3), ("s49152", (2, 32, 32, 48), 4), ("s480", (2, 32, 5, 3), 5)):
+        s = synth.synth_sigma(B, C * h * w, seed=seed).reshape(B, C, h, w).numpy()
+        for q in Q_LEVS:
+            m = O.variance_mask_np(s, q).astype(np.uint8)
+            assert np.array_equal(np.packbits(m.reshape(-1)), gold[f"{name}_q{q}"]), (name, q)
+            if 0 < q < 10:
+                thr = np.array([O.quantile_threshold_np(s[b], q * 0.1) for b in range(B)], dtype=np.float32)
+                assert np.array_equal(thr, gold[f"{name}_q{q}_thr"]), (name, q)      # threshold bit-exact
+    blocks = [synth.synth_sigma(1, 32 * 64, seed=20 + i).reshape(1, 32, 8, 8).numpy() for i in range(10)]
+    for q in (0, 0.5, 2.5, 10):
+        m = O.prog_mask_np(blocks, q).astype(np.uint8)
+        assert np.array_equal(np.packbits(m.reshape(-1)), gold[f"prog_q{q}"])
+
+
+def test_quantile_restatement_equals_torch_quantile():
+    rng = np.random.default_rng(0)
+    for n in (8192, 333, 2):
+        for t in range(6):
+            seg = np.exp(rng.uniform(np.log(0.05), np.log(300), n)).astype(np.float32)
+            if t % 2:
+                seg[rng.integers(0, n, max(1, n // 10))] = seg[0]
+            for pr in (0.01, 0.5, 2.5, 5, 9.99):
+                ref = np.float32(torch.quantile(torch.from_numpy(seg), 1.0 - pr * 0.1).item())
+                assert O.quantile_threshold_np(seg, pr * 0.1) == ref
+    assert np.isnan(O.quantile_threshold_np(np.array([1.0, np.nan, 2.0], dtype=np.float32), 0.5))
+
+
+def test_entropy_ops_match_reference():
+    gold = np.load(os.path.join(GOLD, "entropy_ops.npz"))
+    y, mu = _g((2, 32, 16, 16), 30, 6.0), _g((2, 32, 16, 16), 31, 4.0)
+    sg = synth.synth_sigma(2, 32 * 256, seed=32).reshape(2, 32, 16, 16)
+    assert np.array_equal((torch.round(y - mu) + mu).numpy(), gold["gc_out"])
+    _close(O.gaussian_likelihood(y, sg, mu), gold["gc_lik"], 1e-6)
+    assert np.array_equal(torch.round(y).numpy(), gold["gc_out_nomean"])
+    _close(O.gaussian_likelihood(y, sg, None), gold["gc_lik_nomean"], 1e-6)
+    assert np.array_equal(O.build_indexes(sg).numpy().astype(np.int8), gold["gc_idx"])
+    from vampic.entropy_models import EntropyBottleneck
+    eb = EntropyBottleneck(192)
+    sd = {"e." + k: v for k, v in synth.synth_state_dict(eb.state_dict(), 40).items()}
+    zh, zl = O.eb_forward(sd, _g((2, 192, 4, 6), 41, 5.0), "e.")
+    assert np.array_equal(zh.numpy(), gold["eb_zhat"])
+    _close(zl, gold["eb_lik"], 1e-6)
+
+
+def test_layer_ops_match_reference():
+    from vampic import layers as Ly
+    gold = np.load(os.path.join(GOLD, "layer_ops.npz"))
+    for inv in (False, True):
+        sd = {"g." + k: v for k, v in synth.synth_state_dict(Ly.GDN(192, inverse=inv).state_dict(), 7).items()}
+        _close(O.gdn(sd, "g.", _g((2, 192, 8, 8), 8, 2.0), inv), gold[f"gdn_inv{int(inv)}"])
+    for dim, ws, hw in ((192, 8, (16, 24)), (320, 4, (8, 8))):
+        m = Ly.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=ws // 2)
+        sd = {"a." + k: v for k, v in synth.synth_state_dict(m.state_dict(), 9).items()}
+        _close(O.attention_block(sd, "a.", _g((2, dim) + hw, 10), ws), gold[f"attn_{dim}"])
+    m = Ly.LatentRateReduction(32, True, "middle")
+    sd = {"r." + k: v for k, v in synth.synth_state_dict(m.state_dict(), 11).items()}
+    att = (synth.uniform((2, 32, 8, 8), 15) > 0.5).float()
+    _close(O.rem_block(sd, "r.", _g((2, 32, 8, 8), 12, 3.0), _g((2, 64, 8, 8), 13), _g((2, 64, 8, 8), 14),
+                       torch.cat([att, att], 1)), gold["rem"])
+
+
+def test_forward_single_quality_matches_reference(synth_model_cpu):
+    _, sd = synth_model_cpu
+    gold = np.load(os.path.join(GOLD, "forward_single_quality.npz"))
+    scal = json.load(open(os.path.join(GOLD, "forward_single_quality.json")))
+    for seed in (0, 1):
+        x = synth.synth_image(1, 64, 64, seed=seed)
+        for q in (0, 0.5, 2.5, 10):
+            o = O.forward_single_quality(sd, x, q)
+            tag = f"s{seed}_q{q}"
+            _close(o["x_hat"], gold[tag + "_x_hat"])
+            _close(o["y_hat"], gold[tag + "_y_hat"])
+            _close(o["likelihoods"]["y"], gold[tag + "_lik_y"])
+            _close(o["likelihoods"]["z"], gold[tag + "_lik_z"])
+            assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4
+            assert abs(O.bpp(o["likelihoods"], 64 * 64) - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"])
+    x = synth.synth_image(1, 64, 128, seed=0)
+    ck = O.forward_single_quality(sd, x, 0.75, check_levels=[0.75])["y_hat"]
+    _close(ck, gold["rem_ck"])
+    o = O.forward_single_quality(sd, x, 2.5, check_levels=[0.75], checkpoint_ref=torch.from_numpy(gold["rem_ck"]))
+    _close(o["x_hat"], gold["rem_x_hat"])
+    _close(o["y_hat"], gold["rem_y_hat"])
+    _close(o["likelihoods"]["y"], gold["rem_lik_y"])
