@@ -135,9 +135,18 @@ def main():
         net.use_graph = not a.no_graph
         c = prof["conv_igemm"]
         achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+        traffic = None
+        if (B, H, W) == (32, 256, 256):
+            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            # (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction): scripts/pmc_summary.py
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            if pm:
+                t = json.load(open(pm[-1]))["conv_igemm"]
+                traffic = round(t["traffic_bytes_per_step"] / max(t["launches_per_step"], 1))
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one step)",
                 "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes beyond L2 per launch (avg)",
                 "launches_per_step": c["launches"] // psteps,
                 "avg_launch_us": round(c["ms"] * 1e3 / max(c["launches"], 1), 2),
                 "flop_per_step": c["flops"] / psteps,

@@ -10,15 +10,19 @@
 // * Each K chunk (one tap, BK consecutive channels) of the A tile is BM rows of BK
 //   contiguous floats in HBM/L2 -> coalesced 16-byte loads, zero-filled at the halo,
 //   staged through LDS (row stride BK+4 floats: conflict-free ds_read_b128).
-// * Weights are pre-packed [tap][k-chunk][n][BK] so the B tile is one contiguous block.
+// * Weights are pre-packed [tap][16-channel chunk][n][16] so a B tile is one or two contiguous blocks.
 // * Double-buffered LDS, next chunk prefetched into registers under the MFMAs,
 //   one barrier per chunk.
-// * Grouped launch: up to 8 independent problems share one grid.
+// * Grouped launch: up to 8 independent problems share one grid; tiles are dealt to XCDs in
+//   contiguous runs (blocks b and b+8 share an XCD/L2) so neighbours reuse A rows and halos.
+// * Tile shapes cover the model's channel counts without padding waste: BN in
+//   {32,64,96,128,160,192,224}, BM in {64,128}.
 //
 // Replaces nn.Conv2d / nn.ConvTranspose2d (per sub-pixel phase) / nn.Linear plus the
 // surrounding element-wise ops of reference layers/layers.py:5-86, layers/gdn.py:62-75,
 // layers/rem.py:52-66,130-141, models/pic.py:528-551,598-641.
 #include "common.h"
+#include <cstdlib>
 
 namespace vam {
 
@@ -34,7 +38,7 @@ struct ConvP {
   int Ho, Wo, HoWo;
   int P;        // B*Ho*Wo
   int N, Npad;  // output channels, padded to 32
-  int Cin, Kc;  // total input channels, k-chunks per tap
+  int Cin, Kc, Kc16;  // total input channels, K chunks (of the kernel's BK) per tap, 16-channel packing chunks per tap
   const float* wpack;
   const float* bias;
   float* out;
@@ -66,6 +70,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+constexpr int PK = 16;  // packing granularity of the weight buffer along K
+
 template <int BM, int BN, int BK, int WGM, int WGN>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupArgs args) {
   constexpr int NT = WGM * WGN * 64;         // threads per block
@@ -77,13 +83,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   constexpr int NA = (BM + RPP - 1) / RPP;   // A float4 per thread
   constexpr int NB = (BN + RPP - 1) / RPP;
   constexpr bool A_FULL = (BM % RPP) == 0, B_FULL = (BN % RPP) == 0;
+  static_assert(TM >= 1 && TN >= 1 && BM == TM * WGM * 32 && BN == TN * WGN * 32, "tile/wave layout");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                          // [2][BM][LDS_LD]
   float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
 
-  // ---- which problem / tile
-  int bid = blockIdx.x;
+  // ---- which problem / tile.  XCD-aware remap: hardware deals consecutive block ids
+  // round-robin over the 8 XCDs, so give each XCD a contiguous run of tiles (bijective form).
+  int bid;
+  {
+    const int total = args.tile_start[args.nprob];
+    const int q = total >> 3, r = total & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < VAM_MAX_GROUP; ++i)
@@ -122,12 +136,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
 
   float4 ra[NA], rb[NB];
   const int n_taps = P.kh * P.kw;
-  const int n_chunks = n_taps * P.Kc;
+  const int n_chunks = n_taps * P.Kc;        // Kc = K chunks of BK per tap
+  const int kc16 = P.Kc16;                   // 16-channel packing chunks per tap
 
   // chunk state (block-uniform)
-  int c_ty = 0, c_tx = 0, c_kc = 0, c_seg = 0;
+  int c_ty = 0, c_tx = 0, c_kc = 0, c_seg = 0, c_tap = 0;
 
-  auto gload = [&](int chunk) {
+  auto gload = [&]() {
     const int cc0 = c_kc * BK;
     while (cc0 >= P.seg_end[c_seg]) ++c_seg;
     const int seg_begin = c_seg ? P.seg_end[c_seg - 1] : 0;
@@ -147,18 +162,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
       }
       ra[i] = v;
     }
-    const float* wsrc = P.wpack + ((size_t)chunk * P.Npad + n0) * BK + ld_col;
+    // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
+    const int k16 = c_kc * (BK / PK) + (ld_col >> 4);
+    const bool kok = k16 < kc16;
+    const float* wsrc = P.wpack + (((size_t)c_tap * kc16 + k16) * P.Npad + n0) * PK + (ld_col & 15);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int r = ld_row + i * RPP;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((B_FULL || r < BN) && n0 + r < P.Npad) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * BK);
+      if (kok && (B_FULL || r < BN) && n0 + r < P.Npad) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * PK);
       rb[i] = v;
     }
     // advance chunk state
     if (++c_kc == P.Kc) {
       c_kc = 0;
       c_seg = 0;
+      ++c_tap;
       if (++c_tx == P.kw) { c_tx = 0; ++c_ty; }
     }
   };
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
+  gload();
   sstore(0);
   __syncthreads();
 
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
 
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < n_chunks) gload(ch + 1);
+    if (ch + 1 < n_chunks) gload();
     const float* a = sA + buf * BM * LDS_LD + a_row0;
     const float* b = sB + buf * BN * LDS_LD + b_row0;
 #pragma unroll
@@ -219,23 +238,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
     __syncthreads();
   }
 
-  // ---- epilogue.  Stage the block's C tile through LDS (C layout of the 32x32 MFMA:
-  // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then stream it out with one
-  // float4 of 4 consecutive channels per lane: 16-byte aux loads and stores, and the
-  // activation code exists once instead of once per accumulator register.
+  // ---- epilogue.  The block's C tile goes through LDS one 32-row slab per wave-row at a time
+  // (C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then is
+  // streamed out with one float4 of 4 consecutive channels per lane: 16-byte aux loads and
+  // stores, and the activation code exists once instead of once per accumulator register.
   constexpr int LDC = BN + 4;
+  constexpr int SROWS = WGM * 32;            // rows per slab
   float* sC = smem;  // the pipeline buffers are dead after the last barrier of the loop
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        sC[row * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
-      }
-  __syncthreads();
-
   const bool ps2 = (P.flags & VAM_CONV_PS2) != 0;
   const bool nchw = (P.flags & VAM_CONV_OUT_NCHW) != 0;
   const bool dense = !ps2 && !nchw && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
@@ -243,80 +252,93 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   const bool vec_ok = !nchw && (!ps2 || (P.Cq & 3) == 0);
   const int Cc = ps2 ? P.Cq : P.N;
   const size_t HfWf = (size_t)P.Hf * P.Wf;
-  for (int it = tid; it < BM * (BN / 4); it += NT) {
-    const int row = it / (BN / 4);
-    const int c4 = (it - row * (BN / 4)) * 4;
-    const int p = m0 + row;
-    const int n = n0 + c4;
-    if (p >= P.P || n >= P.N) continue;
-    const float4 av = *reinterpret_cast<const float4*>(sC + row * LDC + c4);
-    float v[4] = {av.x, av.y, av.z, av.w};
-    int ob = 0, oy = 0, ox = 0;
-    if (!dense) {
-      ob = p / P.HoWo;
-      int rr = p - ob * P.HoWo;
-      oy = rr / P.Wo;
-      ox = rr - oy * P.Wo;
-    }
-    if (vec_ok) {
-      int cch = n;
-      size_t opix;
-      if (dense) {
-        opix = (size_t)p;
-      } else if (ps2) {
-        int ph = n / P.Cq;
-        cch = n - ph * P.Cq;
-        opix = ((size_t)ob * P.Hf + 2 * oy + (ph >> 1)) * P.Wf + 2 * ox + (ph & 1);
-      } else {
-        opix = ((size_t)ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
-      }
-      if (P.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (P.pre) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
-        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
-      if (P.mul) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
-        v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
+  for (int i = 0; i < TM; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sC[srow * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
       }
-      if (P.post) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
-        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+    __syncthreads();
+    for (int it = tid; it < SROWS * (BN / 4); it += NT) {
+      const int srow = it / (BN / 4);
+      const int c4 = (it - srow * (BN / 4)) * 4;
+      const int row = (srow >> 5) * (TM * 32) + i * 32 + (srow & 31);   // slab row -> tile row
+      const int p = m0 + row;
+      const int n = n0 + c4;
+      if (p >= P.P || n >= P.N) continue;
+      const float4 av = *reinterpret_cast<const float4*>(sC + srow * LDC + c4);
+      float v[4] = {av.x, av.y, av.z, av.w};
+      int ob = 0, oy = 0, ox = 0;
+      if (!dense) {
+        ob = p / P.HoWo;
+        int rr = p - ob * P.HoWo;
+        oy = rr / P.Wo;
+        ox = rr - oy * P.Wo;
       }
-      if (P.post2) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
-        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-      }
-      *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
-      for (int k = 0; k < 4; ++k) {
-        const int nn = n + k;
-        if (nn >= P.N) break;
-        int cch = nn, oyf, oxf;
-        if (ps2) {
-          int ph = nn / P.Cq;
-          cch = nn - ph * P.Cq;
-          oyf = 2 * oy + (ph >> 1);
-          oxf = 2 * ox + (ph & 1);
+      if (vec_ok) {
+        int cch = n;
+        size_t opix;
+        if (dense) {
+          opix = (size_t)p;
+        } else if (ps2) {
+          int ph = n / P.Cq;
+          cch = n - ph * P.Cq;
+          opix = ((size_t)ob * P.Hf + 2 * oy + (ph >> 1)) * P.Wf + 2 * ox + (ph & 1);
         } else {
-          oyf = oy * P.osy + P.ooy;
-          oxf = ox * P.osx + P.oox;
+          opix = ((size_t)ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
         }
-        const size_t opix = ((size_t)ob * P.Hf + oyf) * P.Wf + oxf;
-        float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
-        if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
-        x = apply_act(x, P.act);
-        if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
-        if (P.post) x = x + P.post[opix * P.ld_post + cch];
-        if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
-        if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (size_t)oyf * P.Wf + oxf] = x;
-        else P.out[opix * P.ldo + cch] = x;
+        if (P.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (P.pre) {
+          const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
+          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
+        if (P.mul) {
+          const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
+          v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
+        }
+        if (P.post) {
+          const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
+          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        }
+        if (P.post2) {
+          const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
+          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        }
+        *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
+        for (int k = 0; k < 4; ++k) {
+          const int nn = n + k;
+          if (nn >= P.N) break;
+          int cch = nn, oyf, oxf;
+          if (ps2) {
+            int ph = nn / P.Cq;
+            cch = nn - ph * P.Cq;
+            oyf = 2 * oy + (ph >> 1);
+            oxf = 2 * ox + (ph & 1);
+          } else {
+            oyf = oy * P.osy + P.ooy;
+            oxf = ox * P.osx + P.oox;
+          }
+          const size_t opix = ((size_t)ob * P.Hf + oyf) * P.Wf + oxf;
+          float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
+          if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
+          x = apply_act(x, P.act);
+          if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
+          if (P.post) x = x + P.post[opix * P.ld_post + cch];
+          if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
+          if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (size_t)oyf * P.Wf + oxf] = x;
+          else P.out[opix * P.ldo + cch] = x;
+        }
       }
     }
   }
@@ -394,12 +416,14 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restric
   dst[i] = v;
 }
 
-static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }
+static int g_force[3] = {0, 0, 0};   // tuning hook: forced BM / BN / BK (0 = automatic)
+
+static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
 
 template <int BM, int BN, int BK, int WGM, int WGN>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   constexpr size_t pipe = 2 * (BM + BN) * (BK + 4) * sizeof(float);
-  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static bool attr_set = false;
   if (!attr_set) {
@@ -417,8 +441,13 @@ using namespace vam;
 
 extern "C" {
 
+int vam_conv_force_tile(int bm, int bn, int bk) {
+  g_force[0] = bm; g_force[1] = bn; g_force[2] = bk;
+  return VAM_OK;
+}
+
 size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
-  int bk = bk_for(cin);
+  int bk = PK;
   int kc = (cin + bk - 1) / bk;
   int npad = (n + 31) / 32 * 32;
   return (size_t)kh * kw * kc * npad * bk;
@@ -433,7 +462,7 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int
   if (mode == VAM_PACK_DECONV5S2 && phase >= 0)
     VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
   if (mode == VAM_PACK_GDN) VAM_REQUIRE(kh == 1 && kw == 1, "GDN pack is 1x1");
-  int bk = bk_for(cin);
+  int bk = PK;
   int kc = (cin + bk - 1) / bk;
   int npad = (n + 31) / 32 * 32;
   long total = (long)kh * kw * kc * npad * bk;
@@ -511,7 +540,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     VAM_REQUIRE(P < (1L << 30) && (long)c.B * c.H * c.W < (1L << 30), "conv[%d]: too many pixels", i);
     p.P = (int)P;
     p.N = c.N; p.Npad = (c.N + 31) / 32 * 32;
-    p.Cin = cin; p.Kc = (cin + pbk - 1) / pbk;
+    p.Cin = cin; p.Kc = (cin + pbk - 1) / pbk; p.Kc16 = (cin + PK - 1) / PK;
     p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
     p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
     p.Cq = c.Cq; p.act = c.act; p.flags = c.flags;
@@ -524,42 +553,65 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     flops += 2.0 * (double)P * c.N * cin * c.kh * c.kw;
     bytes += 4.0 * ((double)c.B * c.H * c.W * cin + (double)P * c.N + (double)c.kh * c.kw * cin * c.N);
   }
-  // tile choice: one configuration per launch, driven by the widest problem
-  int cfg;  // 0:128x128  1:128x64  2:64x64  3:128x32  4:64x32
-  long work128 = 0;
-  for (int i = 0; i < nprob; ++i) work128 += (long)cdiv(ga.p[i].P, 128) * cdiv(ga.p[i].Npad, 128);
-  if (max_n <= 32) cfg = (cdiv(max_p, 128) * (long)nprob >= 512) ? 3 : 4;
-  else if (max_n <= 64) cfg = (cdiv(max_p, 128) * (long)nprob >= 512) ? 1 : 2;
-  else if (work128 >= 384) cfg = 0;
-  else if (work128 * 2 >= 384) cfg = 1;
-  else cfg = 2;
-  static const int BMs[5] = {128, 128, 64, 128, 64}, BNs[5] = {128, 64, 64, 32, 32};
+  // ---- tile choice: one configuration per launch, by a cost score fitted to a sweep of all
+  // (BM,BN,BK) over the model's layer shapes on MI355X (scratch/tune.py; DESIGN.md "Tile choice"):
+  //   score = padded work / real work  x  block-count penalty (fewer than ~4 blocks per CU leaves
+  //   barriers and load latency exposed)  x  tile-shape factor  x  thin-K factor (1x1 layers are
+  //   load-bound: narrow tiles, more blocks in flight).
+  struct Cand { int bm, bn; double shape; };
+  static const Cand cands[14] = {{128, 192, 1.0}, {128, 224, 1.06}, {128, 160, 1.04}, {128, 128, 1.04}, {128, 96, 1.07},
+                                 {128, 64, 1.07}, {128, 32, 1.35}, {64, 192, 1.06}, {64, 128, 1.07}, {64, 64, 1.13},
+                                 {64, 96, 1.3}, {64, 160, 1.35}, {64, 224, 1.6}, {64, 32, 1.7}};
+  int ktot_max = 0;
+  for (int i = 0; i < nprob; ++i) {
+    int kt = ga.p[i].Cin * ga.p[i].kh * ga.p[i].kw;
+    if (kt > ktot_max) ktot_max = kt;
+  }
+  int bm = 128, best_bn = 128;
+  double best_score = -1.0;
+  for (int c = 0; c < 14; ++c) {
+    double padded = 0.0, real = 0.0;
+    long blocks = 0;
+    for (int i = 0; i < nprob; ++i) {
+      long tm_ = cdiv(ga.p[i].P, cands[c].bm), tn_ = cdiv(ga.p[i].Npad, cands[c].bn);
+      blocks += tm_ * tn_;
+      padded += (double)tm_ * cands[c].bm * tn_ * cands[c].bn;
+      real += (double)ga.p[i].P * ga.p[i].N;
+    }
+    double bp = blocks >= 1024 ? 1.0 : blocks >= 512 ? 1.04 : blocks >= 256 ? 1.22 : 1.22 * 256.0 / (double)blocks;
+    double kp = 1.0;
+    if (ktot_max <= 256 && cands[c].bn > 96) kp = 1.3;
+    if (ktot_max <= 256 && cands[c].bn == 96) kp = 1.1;
+    double sc = padded / real * bp * cands[c].shape * kp;
+    if (best_score < 0 || sc < best_score) { best_score = sc; bm = cands[c].bm; best_bn = cands[c].bn; }
+  }
+  if (g_force[0] == 64 || g_force[0] == 128) bm = g_force[0];
+  if (g_force[1] > 0) best_bn = g_force[1];
+  // K step 32 halves the barriers per FLOP; the sweep prefers 16 for the 128x192 tile (LDS for
+  // three resident blocks per CU) and for thin-K layers.
+  if (bk == 32 && (g_force[2] == 16 || (g_force[2] != 32 && ((bm == 128 && best_bn == 192) || ktot_max <= 256)))) {
+    bk = 16;
+    for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
+  }
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     ga.tile_start[i] = total;
-    ga.p[i].tiles_n = cdiv(ga.p[i].Npad, BNs[cfg]);
-    total += cdiv(ga.p[i].P, BMs[cfg]) * ga.p[i].tiles_n;
+    ga.p[i].tiles_n = cdiv(ga.p[i].Npad, best_bn);
+    total += cdiv(ga.p[i].P, bm) * ga.p[i].tiles_n;
   }
   for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
-  if (bk == 32) {
-    switch (cfg) {
-      case 0: return launch_cfg<128, 128, 32, 2, 2>(ga, total, s);
-      case 1: return launch_cfg<128, 64, 32, 2, 2>(ga, total, s);
-      case 2: return launch_cfg<64, 64, 32, 2, 2>(ga, total, s);
-      case 3: return launch_cfg<128, 32, 32, 4, 1>(ga, total, s);
-      default: return launch_cfg<64, 32, 32, 2, 1>(ga, total, s);
-    }
-  } else {
-    switch (cfg) {
-      case 0: return launch_cfg<128, 128, 16, 2, 2>(ga, total, s);
-      case 1: return launch_cfg<128, 64, 16, 2, 2>(ga, total, s);
-      case 2: return launch_cfg<64, 64, 16, 2, 2>(ga, total, s);
-      case 3: return launch_cfg<128, 32, 16, 4, 1>(ga, total, s);
-      default: return launch_cfg<64, 32, 16, 2, 1>(ga, total, s);
-    }
-  }
+#define VAM_CFG(BM_, BN_, WGM_, WGN_)                                                        \
+  if (bm == BM_ && best_bn == BN_)                                                           \
+    return bk == 32 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_>(ga, total, s) : launch_cfg<BM_, BN_, 16, WGM_, WGN_>(ga, total, s);
+  VAM_CFG(128, 32, 4, 1) VAM_CFG(128, 64, 2, 2) VAM_CFG(128, 96, 4, 1) VAM_CFG(128, 128, 2, 2)
+  VAM_CFG(128, 160, 4, 1) VAM_CFG(128, 192, 2, 2) VAM_CFG(128, 224, 4, 1)
+  VAM_CFG(64, 32, 2, 1) VAM_CFG(64, 64, 2, 2) VAM_CFG(64, 96, 2, 1) VAM_CFG(64, 128, 2, 2)
+  VAM_CFG(64, 160, 2, 1) VAM_CFG(64, 192, 2, 2) VAM_CFG(64, 224, 2, 1)
+#undef VAM_CFG
+  set_error("vam_conv_group: no kernel configuration for BM=%d BN=%d", bm, best_bn);
+  return VAM_EINVAL;
 }
 
 }  // extern "C"
