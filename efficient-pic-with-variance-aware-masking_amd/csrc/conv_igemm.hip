@@ -73,7 +73,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 constexpr int PK = 16;  // packing granularity of the weight buffer along K
 
 template <int BM, int BN, int BK, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupArgs args) {
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const GroupArgs args) {
   constexpr int NT = WGM * WGN * 64;         // threads per block
   constexpr int LDS_LD = BK + 4;             // floats per LDS row
   constexpr int TM = BM / WGM / 32;          // 32x32 tiles per wave along M
@@ -89,21 +89,32 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   float* sA = smem;                          // [2][BM][LDS_LD]
   float* sB = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
 
-  // ---- which problem / tile.  XCD-aware remap: hardware deals consecutive block ids
-  // round-robin over the 8 XCDs, so give each XCD a contiguous run of tiles (bijective form).
-  int bid;
+  // ---- which problem / tile.  The hardware deals consecutive block ids round-robin over the 8
+  // XCDs (blocks b and b+8 share an L2).  Every XCD gets a contiguous 1/8 of EACH problem's tiles:
+  // neighbouring tiles (shared A rows / halos) stay on one L2, and problems of unequal cost (the
+  // 9/6/6/4-tap phases of a transposed conv) are balanced across XCDs.  The grid is padded to
+  // 8 x max-per-XCD; surplus blocks exit.
+  int pi = -1, t = 0;
   {
-    const int total = args.tile_start[args.nprob];
-    const int q = total >> 3, r = total & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int pi = 0;
+    const int xcd = blockIdx.x & 7;
+    int idx = blockIdx.x >> 3;
 #pragma unroll
-  for (int i = 1; i < VAM_MAX_GROUP; ++i)
-    if (i < args.nprob && bid >= args.tile_start[i]) pi = i;
+    for (int i = 0; i < VAM_MAX_GROUP; ++i) {
+      if (i < args.nprob && pi < 0) {
+        const int T = args.tile_start[i + 1] - args.tile_start[i];
+        const int q = T >> 3, r = T & 7;
+        const int c = q + (xcd < r ? 1 : 0);
+        if (idx < c) {
+          pi = i;
+          t = xcd * q + (xcd < r ? xcd : r) + idx;
+        } else {
+          idx -= c;
+        }
+      }
+    }
+  }
+  if (pi < 0) return;
   const ConvP& P = args.p[pi];
-  const int t = bid - args.tile_start[pi];
   const int tn = t % P.tiles_n, tm = t / P.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -134,7 +145,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   }
   const bool sq = (P.flags & VAM_CONV_SQUARE_IN) != 0;
 
-  float4 ra[NA], rb[NB];
+  // Two register stages: the loads of chunk k+2 are issued before chunk k is computed and are
+  // written to LDS one iteration later, so a load has two compute phases to land (L2-miss
+  // latency is ~2 us under load; one K chunk of MFMAs is 0.2-1.3 us).
+  float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
   const int n_taps = P.kh * P.kw;
   const int n_chunks = n_taps * P.Kc;        // Kc = K chunks of BK per tap
   const int kc16 = P.Kc16;                   // 16-channel packing chunks per tap
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   // chunk state (block-uniform)
   int c_ty = 0, c_tx = 0, c_kc = 0, c_seg = 0, c_tap = 0;
 
-  auto gload = [&]() {
+  auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
     const int cc0 = c_kc * BK;
     while (cc0 >= P.seg_end[c_seg]) ++c_seg;
     const int seg_begin = c_seg ? P.seg_end[c_seg - 1] : 0;
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
       if (++c_tx == P.kw) { c_tx = 0; ++c_ty; }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* a = sA + buf * BM * LDS_LD;
     float* b = sB + buf * BN * LDS_LD;
 #pragma unroll
@@ -202,17 +216,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload();
-  sstore(0);
-  __syncthreads();
-
   const int l31 = lane & 31, lh = lane >> 5;
   const int a_row0 = (wm * TM * 32 + l31) * LDS_LD + lh * 4;
   const int b_row0 = (wn * TN * 32 + l31) * LDS_LD + lh * 4;
 
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < n_chunks) gload();
+  auto compute = [&](int buf) {
     const float* a = sA + buf * BM * LDS_LD + a_row0;
     const float* b = sB + buf * BN * LDS_LD + b_row0;
 #pragma unroll
@@ -234,7 +242,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (ch + 1 < n_chunks) sstore(buf ^ 1);
+  };
+
+  // prologue: chunk 0 -> LDS[0]; chunk 1 -> stage 0 registers
+  gload(ra0, rb0);
+  sstore(0, ra0, rb0);
+  if (n_chunks > 1) gload(ra0, rb0);
+  __syncthreads();
+  // steady state, unrolled by two so that the register stages are named statically.  At the top of
+  // step ch the LDS buffer ch&1 holds chunk ch and one register stage holds chunk ch+1 (loaded a
+  // whole compute phase ago).  The stage is written to the other LDS buffer FIRST (that buffer's
+  // last readers passed the barrier that ended step ch-1), then chunk ch+2 is requested, then the
+  // MFMAs run: neither the LDS stores nor the global loads sit between the MFMAs and the barrier.
+  for (int ch = 0; ch < n_chunks; ch += 2) {
+    if (ch + 1 < n_chunks) sstore(1, ra0, rb0);
+    if (ch + 2 < n_chunks) gload(ra1, rb1);
+    compute(0);
+    __syncthreads();
+    if (ch + 1 >= n_chunks) break;
+    if (ch + 2 < n_chunks) sstore(0, ra1, rb1);
+    if (ch + 3 < n_chunks) gload(ra0, rb0);
+    compute(1);
     __syncthreads();
   }
 
@@ -245,6 +273,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
   constexpr int LDC = BN + 4;
   constexpr int SROWS = WGM * 32;            // rows per slab
   float* sC = smem;  // the pipeline buffers are dead after the last barrier of the loop
+  int* sPix = reinterpret_cast<int*>(smem + SROWS * LDC);   // per slab row: output pixel index, batch index
   const bool ps2 = (P.flags & VAM_CONV_PS2) != 0;
   const bool nchw = (P.flags & VAM_CONV_OUT_NCHW) != 0;
   const bool dense = !ps2 && !nchw && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
@@ -262,6 +291,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
         const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         sC[srow * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
       }
+    // one thread per slab row decodes the output position (the integer divisions happen once
+    // per row, not once per element): pixel index within the full output, and batch index
+    if (tid < SROWS) {
+      const int row = (tid >> 5) * (TM * 32) + i * 32 + (tid & 31);
+      const int p = m0 + row;
+      int pix = p, ob = 0;
+      if (!dense && p < P.P) {
+        ob = p / P.HoWo;
+        int rr = p - ob * P.HoWo;
+        int oy = rr / P.Wo;
+        int ox = rr - oy * P.Wo;
+        if (ps2) pix = (ob * P.Hf + 2 * oy) * P.Wf + 2 * ox;
+        else pix = (ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
+      }
+      sPix[2 * tid] = pix;
+      sPix[2 * tid + 1] = ob;
+    }
     __syncthreads();
     for (int it = tid; it < SROWS * (BN / 4); it += NT) {
       const int srow = it / (BN / 4);
@@ -272,24 +318,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
       if (p >= P.P || n >= P.N) continue;
       const float4 av = *reinterpret_cast<const float4*>(sC + srow * LDC + c4);
       float v[4] = {av.x, av.y, av.z, av.w};
-      int ob = 0, oy = 0, ox = 0;
-      if (!dense) {
-        ob = p / P.HoWo;
-        int rr = p - ob * P.HoWo;
-        oy = rr / P.Wo;
-        ox = rr - oy * P.Wo;
-      }
+      const int pixb = sPix[2 * srow], ob = sPix[2 * srow + 1];
       if (vec_ok) {
         int cch = n;
-        size_t opix;
-        if (dense) {
-          opix = (size_t)p;
-        } else if (ps2) {
+        size_t opix = (size_t)pixb;
+        if (ps2) {
           int ph = n / P.Cq;
           cch = n - ph * P.Cq;
-          opix = ((size_t)ob * P.Hf + 2 * oy + (ph >> 1)) * P.Wf + 2 * ox + (ph & 1);
-        } else {
-          opix = ((size_t)ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
+          opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
         }
         if (P.bias) {
           const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
@@ -319,24 +355,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const GroupA
         for (int k = 0; k < 4; ++k) {
           const int nn = n + k;
           if (nn >= P.N) break;
-          int cch = nn, oyf, oxf;
+          int cch = nn;
+          size_t opix = (size_t)pixb;
           if (ps2) {
             int ph = nn / P.Cq;
             cch = nn - ph * P.Cq;
-            oyf = 2 * oy + (ph >> 1);
-            oxf = 2 * ox + (ph & 1);
-          } else {
-            oyf = oy * P.osy + P.ooy;
-            oxf = ox * P.osx + P.oox;
+            opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
           }
-          const size_t opix = ((size_t)ob * P.Hf + oyf) * P.Wf + oxf;
           float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
           if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
           x = apply_act(x, P.act);
           if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
           if (P.post) x = x + P.post[opix * P.ld_post + cch];
           if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
-          if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (size_t)oyf * P.Wf + oxf] = x;
+          if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (opix - (size_t)ob * HfWf)] = x;
           else P.out[opix * P.ldo + cch] = x;
         }
       }
@@ -423,7 +455,7 @@ static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // ker
 template <int BM, int BN, int BK, int WGM, int WGN>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   constexpr size_t pipe = 2 * (BM + BN) * (BK + 4) * sizeof(float);
-  constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float);
+  constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float) + (size_t)WGM * 32 * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static bool attr_set = false;
   if (!attr_set) {
@@ -431,7 +463,11 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN>), dim3(total_tiles), dim3(WGM * WGN * 64), smem, s, ga);
+  // grid: 8 XCD groups x the largest per-XCD share (see the kernel's tile mapping)
+  int per_xcd = 0;
+  for (int i = 0; i < ga.nprob; ++i) per_xcd += (ga.tile_start[i + 1] - ga.tile_start[i] + 7) / 8;
+  (void)total_tiles;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
   return check_launch("conv_igemm_kernel");
 }
 
@@ -589,7 +625,9 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   if (g_force[1] > 0) best_bn = g_force[1];
   // K step 32 halves the barriers per FLOP; the sweep prefers 16 for the 128x192 tile (LDS for
   // three resident blocks per CU) and for thin-K layers.
-  if (bk == 32 && (g_force[2] == 16 || (g_force[2] != 32 && ((bm == 128 && best_bn == 192) || ktot_max <= 256)))) {
+  // (BN=224 and the two-wave 64x160 tile would spill at BK=32 with two register stages.)
+  if (bk == 32 && (g_force[2] == 16 || best_bn == 224 || (bm == 64 && best_bn == 160) ||
+                   (g_force[2] != 32 && ((bm == 128 && best_bn == 192) || ktot_max <= 256)))) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }

@@ -35,6 +35,10 @@ class Plan:
         self._graph: Optional[ops.Graph] = None
         self.flops = 0.0
         self.meta: List[dict] = []            # one entry per step: what it is and its algorithmic FLOP
+        self.branch_of: List[int] = []        # stream branch of each step (0 = the caller's stream)
+        self.cur_branch = 0
+        self.n_events = 0
+        self._side: Dict[int, "torch.cuda.Stream"] = {}
 
     # ---- buffers
     def buf(self, B, H, W, C, zero=False) -> View:
@@ -58,11 +62,32 @@ class Plan:
             c0 = chunk[0]
             self.meta.append({"kind": "conv", "flops": fl, "desc": f"{n}x[{sum(c0.seg[k].C for k in range(c0.n_seg))}->{c0.N} "
                               f"k{c0.kh}x{c0.kw} s{c0.stride} P={c0.B * c0.Ho * c0.Wo}]"})
+            self.branch_of.append(self.cur_branch)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
     def call(self, fn: Callable[[], None], desc: str = "op"):
         self.meta.append({"kind": "op", "flops": 0.0, "desc": desc})
+        self.branch_of.append(self.cur_branch)
         self.steps.append(fn)
+
+    # ---- concurrency: independent chains are recorded on different branches (HIP streams) and
+    # ordered by events; under capture they become parallel branches of the hipGraph.
+    def branch(self, b: int):
+        self.cur_branch = b
+
+    def record(self) -> int:
+        """Mark "everything recorded so far on the current branch is done"; returns an event id."""
+        idx = self.n_events
+        self.n_events += 1
+        self.meta.append({"kind": "event", "flops": 0.0, "desc": f"record {idx}"})
+        self.branch_of.append(self.cur_branch)
+        self.steps.append(("rec", idx))
+        return idx
+
+    def wait(self, idx: int):
+        self.meta.append({"kind": "event", "flops": 0.0, "desc": f"wait {idx}"})
+        self.branch_of.append(self.cur_branch)
+        self.steps.append(("wait", idx))
 
     def profile(self, reps: int = 3):
         """Per-step time (ms, best of reps) measured with events on the current stream."""
@@ -72,7 +97,8 @@ class Plan:
             for s in self.steps:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                s()
+                if not isinstance(s, tuple):      # single-stream replay: events are no-ops
+                    s()
                 b.record()
                 evs.append((a, b))
             torch.cuda.current_stream().synchronize()
@@ -81,8 +107,33 @@ class Plan:
 
     # ---- execution
     def run(self):
-        for s in self.steps:
-            s()
+        main = torch.cuda.current_stream(self.device)
+        if self.n_events == 0:
+            for s in self.steps:
+                s()
+            return
+        streams = {0: main}
+        for b in set(self.branch_of):
+            if b != 0:
+                if b not in self._side:
+                    self._side[b] = torch.cuda.Stream(device=self.device)
+                streams[b] = self._side[b]
+        events = [torch.cuda.Event() for _ in range(self.n_events)]
+        cur = 0
+        try:
+            for b, s in zip(self.branch_of, self.steps):
+                if b != cur:
+                    torch.cuda.set_stream(streams[b])
+                    cur = b
+                if isinstance(s, tuple):
+                    if s[0] == "rec":
+                        events[s[1]].record(streams[b])
+                    else:
+                        streams[b].wait_event(events[s[1]])
+                else:
+                    s()
+        finally:
+            torch.cuda.set_stream(main)
 
     def graph_run(self):
         if self._graph is None:

@@ -441,10 +441,17 @@ class _FsqPlan:
                            [sl(yb, i) for i in idx],
                            [dict(act=L.ACT_HALF_TANH, post=sl(yq, i)) for i in idx])
 
+        base_done = {}                                   # slice -> event "its y_hat_base is final"
         for i in range(min(ns, m.max_support_slices)):
             base_group([i])
+            if not base_only:
+                base_done[i] = plan.record()
         if ns > m.max_support_slices:
             base_group(list(range(m.max_support_slices, ns)))   # slices 5..9 only see slices 0..4
+            if not base_only:
+                ev = plan.record()
+                for i in range(m.max_support_slices, ns):
+                    base_done[i] = ev
 
         if base_only:
             E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
@@ -457,7 +464,11 @@ class _FsqPlan:
         mu_tot = plan.buf(B, h, w, d)
         sp = m.support_progressive_slices
         msups, ssups = [], []
+        # With all_scalable the progressive mu/sigma chain only needs y_hat_base[j] and its own history
+        # (pic.py:586-612), so it runs on a second HIP stream concurrently with base slices > j.
+        plan.branch(1)
         for j in range(ns):
+            plan.wait(base_done[j])
             s = min(sp, j)
             ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else [])
             ss = [sh1, sl(yb, j)] + ([sl(self.std_p, j - s, s)] if s else [])
@@ -466,6 +477,9 @@ class _FsqPlan:
             E.lower_stacks(plan, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss],
                            [sl(self.mu_p, j), sl(self.std_p, j)])
             plan.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)))       # pic.py:603
+        chain_done = plan.record()
+        plan.branch(0)
+        plan.wait(chain_done)
 
         mu_f, std_f = self.mu_p, self.std_p
         if rem_idx is not None:                                                       # rem_pic.py:363-377
