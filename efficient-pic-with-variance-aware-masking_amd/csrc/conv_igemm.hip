@@ -27,6 +27,7 @@
 namespace vam {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvP {
   const float* seg_ptr[VAM_MAX_SEG];
@@ -124,25 +125,41 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const int ld_row = tid / CPR;              // row within a pass
   const int ld_col = (tid % CPR) * 4;        // float offset within the chunk
 
-  // ---- per-thread A rows: decode output position once
-  int a_iy0[NA], a_ix0[NA], a_boff[NA];
+  // ---- per-thread A rows: decode the output position once.  a_pix0 = input pixel index of tap
+  // (0,0); a_mask bit t = tap t of this row lies inside the image (zero padding otherwise).
+  int a_pix0[NA];
+  unsigned a_mask[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int p = m0 + ld_row + i * RPP;
+    a_pix0[i] = 0;
+    a_mask[i] = 0u;
     if (p < P.P && (A_FULL || ld_row + i * RPP < BM)) {
       int b = p / P.HoWo;
       int r = p - b * P.HoWo;
       int oy = r / P.Wo;
       int ox = r - oy * P.Wo;
-      a_iy0[i] = oy * P.stride - P.pad_y;
-      a_ix0[i] = ox * P.stride - P.pad_x;
-      a_boff[i] = b * P.HW;
-    } else {
-      a_iy0[i] = -(1 << 28);
-      a_ix0[i] = 0;
-      a_boff[i] = 0;
+      const int iy0 = oy * P.stride - P.pad_y, ix0 = ox * P.stride - P.pad_x;
+      a_pix0[i] = b * P.HW + iy0 * P.W + ix0;
+      unsigned m = 0u;
+      for (int ty = 0; ty < P.kh; ++ty)
+        for (int tx = 0; tx < P.kw; ++tx)
+          if ((unsigned)(iy0 + ty) < (unsigned)P.H && (unsigned)(ix0 + tx) < (unsigned)P.W) m |= 1u << (ty * P.kw + tx);
+      a_mask[i] = m;
     }
   }
+  // B rows: byte offset inside one [16-chunk][Npad][16] slab of the packed weights (constant per thread)
+  unsigned b_off[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = ld_row + i * RPP;
+    const bool ok = (B_FULL || r < BN) && (n0 + r < P.Npad);
+    b_off[i] = ok ? (unsigned)((((ld_col >> 4) * P.Npad + n0 + r) * PK + (ld_col & 15)) * 4) : 0x80000000u;
+  }
+  const unsigned long long wpa = reinterpret_cast<unsigned long long>(P.wpack);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(wpa >> 32)) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)wpa)), 0, 0x7FFFFFFF, 0x00020000);
   const bool sq = (P.flags & VAM_CONV_SQUARE_IN) != 0;
 
   // Two register stages: the loads of chunk k+2 are issued before chunk k is computed and are
@@ -154,43 +171,46 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const int kc16 = P.Kc16;                   // 16-channel packing chunks per tap
 
   // chunk state (block-uniform)
-  int c_ty = 0, c_tx = 0, c_kc = 0, c_seg = 0, c_tap = 0;
+  int c_ty = 0, c_tx = 0, c_kc = 0, c_tap = 0;
 
+  // Global -> register stage through buffer loads: 32-bit per-lane byte offsets against a
+  // wave-uniform descriptor, and the halo/tail zero-fill comes from the hardware range check
+  // (an offset of 2^31 is out of range and returns 0) instead of branches.
   auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
     const int cc0 = c_kc * BK;
-    while (cc0 >= P.seg_end[c_seg]) ++c_seg;
+    // segment holding channel cc0 (unused segments end at 2^30); branch-free and explicitly uniform
+    const int c_seg = __builtin_amdgcn_readfirstlane((cc0 >= P.seg_end[0] ? 1 : 0) + (cc0 >= P.seg_end[1] ? 1 : 0) +
+                                                     (cc0 >= P.seg_end[2] ? 1 : 0));
     const int seg_begin = c_seg ? P.seg_end[c_seg - 1] : 0;
-    const float* sp = P.seg_ptr[c_seg];
-    const int sld = P.seg_ld[c_seg];
-    const int coff = cc0 - seg_begin + ld_col;
-    const bool cok = (cc0 + ld_col) < P.Cin;
+    // readfirstlane makes the descriptor PROVABLY wave-uniform; without it hipcc wraps every
+    // buffer load in a waterfall loop with a vmcnt(0) in between (cdna guide T20).
+    const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[c_seg]);
+    const unsigned sp_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);          // the builtin returns a signed int:
+    const unsigned sp_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));  // keep the halves unsigned
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)sp_hi << 32) | sp_lo), 0, 0x7FFFFFFF, 0x00020000);
+    const int sld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[c_seg]) * 4;
+    const int tap_pix = c_ty * P.W + c_tx;                         // uniform
+    const int col4 = (cc0 - seg_begin + ld_col) * 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int iy = a_iy0[i] + c_ty, ix = a_ix0[i] + c_tx;
-      bool ok = cok && ((unsigned)iy < (unsigned)P.H) && ((unsigned)ix < (unsigned)P.W);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const float* src = sp + (size_t)(a_boff[i] + iy * P.W + ix) * sld + coff;
-        v = *reinterpret_cast<const float4*>(src);
-        if (sq) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
-      }
-      ra[i] = v;
+      const bool ok = (a_mask[i] >> c_tap) & 1u;
+      const unsigned off = (unsigned)((a_pix0[i] + tap_pix) * sld4 + col4);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(ok ? off : 0x80000000u), 0, 0);
+      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      if (sq) { f.x *= f.x; f.y *= f.y; f.z *= f.z; f.w *= f.w; }
+      ra[i] = f;
     }
     // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
-    const int k16 = c_kc * (BK / PK) + (ld_col >> 4);
-    const bool kok = k16 < kc16;
-    const float* wsrc = P.wpack + (((size_t)c_tap * kc16 + k16) * P.Npad + n0) * PK + (ld_col & 15);
+    const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * P.Npad * (PK * 4));   // uniform
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      int r = ld_row + i * RPP;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && (B_FULL || r < BN) && n0 + r < P.Npad) v = *reinterpret_cast<const float4*>(wsrc + (size_t)r * PK);
-      rb[i] = v;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_off[i] + wbase), 0, 0);
+      rb[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
     // advance chunk state
     if (++c_kc == P.Kc) {
       c_kc = 0;
-      c_seg = 0;
       ++c_tap;
       if (++c_tx == P.kw) { c_tx = 0; ++c_ty; }
     }
@@ -544,7 +564,10 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       }
     }
     int pbk = bk_for(cin);
-    VAM_REQUIRE(cin % 4 == 0, "conv[%d]: Cin %d not a multiple of 4", i, cin);
+    VAM_REQUIRE(cin % 16 == 0, "conv[%d]: Cin %d not a multiple of 16", i, cin);
+    for (int sgi = 0; sgi < c.n_seg; ++sgi)
+      VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * 4.0 < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
+    VAM_REQUIRE((double)vam_conv_wpack_floats(c.kh, c.kw, cin, c.N) * 4.0 < 2147000000.0, "conv[%d]: packed weights larger than 2 GiB", i);
     for (int s = 0; s + 1 < c.n_seg; ++s)
       VAM_REQUIRE(p.seg_end[s] % pbk == 0, "conv[%d]: segment boundary %d not a multiple of BK=%d", i, p.seg_end[s], pbk);
     if (i == 0) bk = pbk;
