@@ -198,8 +198,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       const unsigned off = (unsigned)((a_pix0[i] + tap_pix) * sld4 + col4);
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(ok ? off : 0x80000000u), 0, 0);
       float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-      if (sq) { f.x *= f.x; f.y *= f.y; f.z *= f.z; f.w *= f.w; }
-      ra[i] = f;
+      ra[i] = sq ? make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w) : f;   // GDN pools x^2 (select, no branch)
     }
     // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
     const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * P.Npad * (PK * 4));   // uniform
@@ -208,12 +207,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_off[i] + wbase), 0, 0);
       rb[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    // advance chunk state
-    if (++c_kc == P.Kc) {
-      c_kc = 0;
-      ++c_tap;
-      if (++c_tx == P.kw) { c_tx = 0; ++c_ty; }
-    }
+    // advance chunk state (branch-free: the steady-state loop body must stay one basic block so
+    // the steady state stays straight-line code)
+    ++c_kc;
+    const int wk = (c_kc == P.Kc) ? 1 : 0;
+    c_kc = wk ? 0 : c_kc;
+    c_tap += wk;
+    c_tx += wk;
+    const int wx = (c_tx == P.kw) ? 1 : 0;
+    c_tx = wx ? 0 : c_tx;
+    c_ty += wx;
   };
   auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* a = sA + buf * BM * LDS_LD;
@@ -274,7 +277,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   // whole compute phase ago).  The stage is written to the other LDS buffer FIRST (that buffer's
   // last readers passed the barrier that ended step ch-1), then chunk ch+2 is requested, then the
   // MFMAs run: neither the LDS stores nor the global loads sit between the MFMAs and the barrier.
-  for (int ch = 0; ch < n_chunks; ch += 2) {
+  int ch = 0;
+  // steady state (no conditionals: chunks ch+1..ch+3 all exist)
+  for (; ch + 3 < n_chunks; ch += 2) {
+    sstore(1, ra0, rb0);
+    gload(ra1, rb1);
+    compute(0);
+    __syncthreads();
+    sstore(0, ra1, rb1);
+    gload(ra0, rb0);
+    compute(1);
+    __syncthreads();
+  }
+  // tail: at most three chunks left
+  for (; ch < n_chunks; ch += 2) {
     if (ch + 1 < n_chunks) sstore(1, ra0, rb0);
     if (ch + 2 < n_chunks) gload(ra1, rb1);
     compute(0);
@@ -618,9 +634,9 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   //   barriers and load latency exposed)  x  tile-shape factor  x  thin-K factor (1x1 layers are
   //   load-bound: narrow tiles, more blocks in flight).
   struct Cand { int bm, bn; double shape; };
-  static const Cand cands[14] = {{128, 192, 1.0}, {128, 224, 1.06}, {128, 160, 1.04}, {128, 128, 1.04}, {128, 96, 1.07},
-                                 {128, 64, 1.07}, {128, 32, 1.35}, {64, 192, 1.06}, {64, 128, 1.07}, {64, 64, 1.13},
-                                 {64, 96, 1.3}, {64, 160, 1.35}, {64, 224, 1.6}, {64, 32, 1.7}};
+  static const Cand cands[14] = {{128, 192, 1.0}, {128, 224, 1.04}, {128, 160, 1.04}, {128, 128, 1.06}, {128, 96, 1.04},
+                                 {128, 64, 1.10}, {128, 32, 1.35}, {64, 192, 1.05}, {64, 128, 1.04}, {64, 64, 1.05},
+                                 {64, 96, 1.12}, {64, 160, 1.35}, {64, 224, 1.6}, {64, 32, 1.5}};
   int ktot_max = 0;
   for (int i = 0; i < nprob; ++i) {
     int kt = ga.p[i].Cin * ga.p[i].kh * ga.p[i].kw;
@@ -637,7 +653,10 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       padded += (double)tm_ * cands[c].bm * tn_ * cands[c].bn;
       real += (double)ga.p[i].P * ga.p[i].N;
     }
-    double bp = blocks >= 1024 ? 1.0 : blocks >= 512 ? 1.04 : blocks >= 256 ? 1.22 : 1.22 * 256.0 / (double)blocks;
+    double bp = blocks >= 1024 ? 1.0 : blocks >= 512 ? 1.04 : blocks >= 256 ? 1.10 : 1.10 * 256.0 / (double)blocks;
+    // the widest tiles run two blocks per CU: below 512 blocks part of the chip holds a single
+    // 4-wave block per CU and the launch runs at that block's pace
+    if (cands[c].bm == 128 && cands[c].bn >= 160 && blocks < 512) bp *= 1.18;
     double kp = 1.0;
     if (ktot_max <= 256 && cands[c].bn > 96) kp = 1.3;
     if (ktot_max <= 256 && cands[c].bn == 96) kp = 1.1;
@@ -650,7 +669,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   // three resident blocks per CU) and for thin-K layers.
   // (BN=224 and the two-wave 64x160 tile would spill at BK=32 with two register stages.)
   if (bk == 32 && (g_force[2] == 16 || best_bn == 224 || (bm == 64 && best_bn == 160) ||
-                   (g_force[2] != 32 && ((bm == 128 && best_bn == 192) || ktot_max <= 256)))) {
+                   (g_force[2] != 32 && ((bm == 128 && (best_bn == 192 || best_bn == 96)) || ktot_max <= 256)))) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }
