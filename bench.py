@@ -150,6 +150,7 @@ def main():
                 "launches_per_step": c["launches"] // psteps,
                 "avg_launch_us": round(c["ms"] * 1e3 / max(c["launches"], 1), 2),
                 "flop_per_step": c["flops"] / psteps,
+                "algorithmic_bytes_per_launch": round(c["bytes"] / max(c["launches"], 1)),
                 "kernel_ms_per_step": {k: round(v["ms"] / psteps, 3) for k, v in prof.items()},
                 "whole_step_tflops": round(FLOP_PER_PIXEL * B * H * W / (ms_step * 1e-3) / 1e12, 3)}
 

@@ -209,14 +209,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     }
     // advance chunk state (branch-free: the steady-state loop body must stay one basic block so
     // the steady state stays straight-line code)
-    ++c_kc;
-    const int wk = (c_kc == P.Kc) ? 1 : 0;
-    c_kc = wk ? 0 : c_kc;
-    c_tap += wk;
-    c_tx += wk;
+    // K order: channel chunk OUTER, tap INNER.  All kh*kw taps of one 16/32-channel chunk touch
+    // the same input pixels (64-128 B of each), so a block's working set between re-touches is
+    // ~60 KB instead of the whole halo x all channels, and the re-reads hit the XCD's L2
+    // instead of going back out to the fabric.
+    ++c_tap;
+    ++c_tx;
     const int wx = (c_tx == P.kw) ? 1 : 0;
     c_tx = wx ? 0 : c_tx;
     c_ty += wx;
+    const int wt = (c_tap == n_taps) ? 1 : 0;
+    c_tap = wt ? 0 : c_tap;
+    c_ty = wt ? 0 : c_ty;
+    c_kc += wt;
   };
   auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* a = sA + buf * BM * LDS_LD;
