@@ -75,10 +75,14 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_gauss_tail": (C.c_int, [C.c_void_p, C.c_int] * 5 + [C.c_void_p, C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_build_indexes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
-    "vam_eb_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p]),
+    "vam_eb_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p]),
+    "vam_dequantize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vam_sqdiff_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
+    "vam_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vam_rans_encode": (C.c_long, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
+    "vam_rans_decode": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vam_graph_begin": (C.c_int, [C.c_void_p]),
     "vam_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "vam_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -209,19 +209,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     }
     // advance chunk state (branch-free: the steady-state loop body must stay one basic block so
     // the steady state stays straight-line code)
-    // K order: channel chunk OUTER, tap INNER.  All kh*kw taps of one 16/32-channel chunk touch
-    // the same input pixels (64-128 B of each), so a block's working set between re-touches is
-    // ~60 KB instead of the whole halo x all channels, and the re-reads hit the XCD's L2
-    // instead of going back out to the fabric.
-    ++c_tap;
-    ++c_tx;
-    const int wx = (c_tx == P.kw) ? 1 : 0;
-    c_tx = wx ? 0 : c_tx;
-    c_ty += wx;
-    const int wt = (c_tap == n_taps) ? 1 : 0;
-    c_tap = wt ? 0 : c_tap;
-    c_ty = wt ? 0 : c_ty;
-    c_kc += wt;
+    // K order (canonical, identical for every tile shape and for BK = 16 or 32, so a layer gives
+    // bit-identical results however it is tiled or grouped — the decoder must reproduce the
+    // encoder's sigma exactly):  32-channel group OUTER, tap MIDDLE, 16-channel half INNER.
+    // All kh*kw taps of one group touch the same input pixels (128 B of each), so a block's
+    // working set between re-touches is ~100 KB instead of the whole halo x all channels and the
+    // re-reads hit the XCD's L2 instead of going back out to the fabric.
+    if (BK == 16) {
+      const int has_half = (((c_kc & 1) == 0) && (c_kc + 1 < kc16)) ? 1 : 0;   // second half of this group exists
+      const int adv_tap = has_half ? 0 : 1;
+      c_kc += has_half;                      // (g, tap, 0) -> (g, tap, 1)
+      c_tap += adv_tap;
+      c_tx += adv_tap;
+      const int wx = (c_tx == P.kw) ? 1 : 0;
+      c_tx = wx ? 0 : c_tx;
+      c_ty += wx;
+      const int wt = (c_tap == n_taps) ? 1 : 0;
+      c_tap = wt ? 0 : c_tap;
+      c_ty = wt ? 0 : c_ty;
+      // next tap of the same group restarts at the group's first half; next group starts after it
+      c_kc = adv_tap ? (wt ? (c_kc | 1) + 1 : (c_kc & ~1)) : c_kc;
+    } else {
+      ++c_tap;
+      ++c_tx;
+      const int wx = (c_tx == P.kw) ? 1 : 0;
+      c_tx = wx ? 0 : c_tx;
+      c_ty += wx;
+      const int wt = (c_tap == n_taps) ? 1 : 0;
+      c_tap = wt ? 0 : c_tap;
+      c_ty = wt ? 0 : c_ty;
+      c_kc += wt;
+    }
   };
   auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* a = sA + buf * BM * LDS_LD;

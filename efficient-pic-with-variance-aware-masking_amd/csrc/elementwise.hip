@@ -221,7 +221,7 @@ __device__ __forceinline__ float eb_logits(const float* sp /*61 preprocessed flo
 
 __global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ params, int C,
                                   float* __restrict__ zhat, int ld_zhat, float* __restrict__ lik, int ld_lik,
-                                  double* log2sum, int pix_per_item, long n_pix) {
+                                  int32_t* __restrict__ sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix) {
   // one thread per channel (blockDim.x >= C), pixels strided over blockIdx / y
   extern __shared__ float sh[];  // C * 62 floats of preprocessed params
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -259,7 +259,9 @@ __global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const f
   const float med = sp[58];
   for (long p = blockIdx.x; p < n_pix; p += gridDim.x) {
     float v = z[p * ld_z + c];
-    float o = rintf(v - med) + med;               // quantize "dequantize" with medians
+    const float qz = rintf(v - med);
+    float o = qz + med;                           // quantize "dequantize" with medians
+    if (sym) sym[p * ld_sym + c] = (int)qz;       // quantize "symbols" (entropy_models.py:151-153)
     float lower = eb_logits(sp, o - 0.5f);
     float upper = eb_logits(sp, o + 0.5f);
     float sum = lower + upper;
@@ -281,6 +283,18 @@ __global__ void add_kernel(const float* __restrict__ a, int ld_a, const float* _
     float4 x = *reinterpret_cast<const float4*>(a + p * ld_a + c);
     float4 y = *reinterpret_cast<const float4*>(b + p * ld_b + c);
     *reinterpret_cast<float4*>(out + p * ld_out + c) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+__global__ void dequantize_kernel(const int32_t* __restrict__ sym, int ld_sym, const float* __restrict__ mu, int ld_mu,
+                                  float* __restrict__ out, int ld_out, long n_vec, int C4) {
+  // EntropyModel.dequantize (entropy_models.py:161-168): float(symbols) + means
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    int4 q = *reinterpret_cast<const int4*>(sym + p * ld_sym + c);
+    float4 m = mu ? *reinterpret_cast<const float4*>(mu + p * ld_mu + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + p * ld_out + c) = make_float4((float)q.x + m.x, (float)q.y + m.y, (float)q.z + m.z, (float)q.w + m.w);
   }
 }
 
@@ -367,7 +381,7 @@ int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int l
 }
 
 int vam_eb_forward(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat, float* lik,
-                   int ld_lik, double* log2sum, int pix_per_item, long n_pix, void* stream) {
+                   int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix, void* stream) {
   VAM_REQUIRE(z && params && C > 0 && C <= 1024 && n_pix > 0, "vam_eb_forward: bad arguments");
   VAM_REQUIRE(!log2sum || pix_per_item > 0, "vam_eb_forward: pix_per_item");
   int block = (C + 63) / 64 * 64;
@@ -376,7 +390,7 @@ int vam_eb_forward(const float* z, int ld_z, const float* params, int C, float* 
   unsigned grid = (unsigned)(n_pix < 1024 ? n_pix : 1024);
   ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
   hipLaunchKernelGGL(eb_forward_kernel, dim3(grid), dim3(block), smem, (hipStream_t)stream, z, ld_z, params, C, zhat,
-                     ld_zhat, lik, ld_lik, log2sum, pix_per_item, n_pix);
+                     ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix);
   return check_launch("eb_forward_kernel");
 }
 
@@ -389,6 +403,17 @@ int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int 
   hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, ld_a, b, ld_b,
                      out, ld_out, n_vec, C / 4);
   return check_launch("add_kernel");
+}
+
+int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, float* out, int ld_out, long n_pix, int C,
+                   void* stream) {
+  VAM_REQUIRE(sym && out && n_pix > 0 && C > 0 && C % 4 == 0 && ld_sym % 4 == 0 && ld_out % 4 == 0 && (!mu || ld_mu % 4 == 0), "vam_dequantize: bad arguments");
+  VAM_REQUIRE(al16(sym) && al16(mu) && al16(out), "vam_dequantize: alignment");
+  long n_vec = n_pix * (C / 4);
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
+  hipLaunchKernelGGL(dequantize_kernel, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, sym, ld_sym, mu,
+                     ld_mu, out, ld_out, n_vec, C / 4);
+  return check_launch("dequantize_kernel");
 }
 
 int vam_memset_zero(void* ptr, size_t bytes, void* stream) {

@@ -2,8 +2,8 @@
 
 ``GaussianConditional`` and ``EntropyBottleneck`` keep the reference's parameter /
 buffer names; likelihood, quantisation and index building run as libvampic kernels.
-The rANS bitstream (``compress`` / ``decompress`` / ``update``) is SURVEY §8(f) row 1
-("next") and is not built in this round: those methods raise.
+The bitstream layer (``update`` CDF tables, ``compress`` / ``decompress``)
+runs the rANS coder of ``csrc/rans.cpp`` on the host, where the reference runs compressai's.
 """
 from __future__ import annotations
 
@@ -11,14 +11,16 @@ import math
 from typing import Optional
 
 import numpy as np
+import scipy.stats
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import bitstream as bs
 from . import ops
 from .layers import _LowerBound, _no_autograd
 
-_NOT_BUILT = ("the rANS bitstream layer (CDF tables + range coder, reference entropy_models.py:206-294,358-396,"
-              "591-618) is a 'next' row of SURVEY §8(f) and is not built yet")
+_NOT_BUILT = "training-mode paths (noise, autograd, aux loss) need the backward kernels (SURVEY K14); not built yet"
 
 
 class EntropyModel(nn.Module):
@@ -74,11 +76,59 @@ class EntropyModel(nn.Module):
             outputs = inputs.float()
         return outputs
 
-    def compress(self, *a, **k):
-        raise NotImplementedError(_NOT_BUILT)
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        """entropy_models.py:175-183."""
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[: pmf_length[i]], tail_mass[i]), dim=0)
+            _cdf = bs.pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+            cdf[i, : _cdf.size(0)] = _cdf
+        return cdf
 
-    def decompress(self, *a, **k):
-        raise NotImplementedError(_NOT_BUILT)
+    def _check_tables(self):
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if len(self._quantized_cdf.size()) != 2:
+            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
+        if self._offset.numel() == 0 or len(self._offset.size()) != 1:
+            raise ValueError("Uninitialized offsets. Run update() first")
+        if self._cdf_length.numel() == 0 or len(self._cdf_length.size()) != 1:
+            raise ValueError("Uninitialized CDF lengths. Run update() first")
+
+    def compress(self, inputs, indexes, means=None, flag=1, already_quantize=False):
+        """entropy_models.py:206-242: one rANS stream per batch element."""
+        if len(inputs.size()) < 2:
+            raise ValueError("Invalid `inputs` size. Expected a tensor with at least 2 dimensions.")
+        symbols = inputs if already_quantize else self.quantize(inputs, "symbols", means)
+        if symbols.size() != indexes.size():
+            raise ValueError("`inputs` and `indexes` should have the same size.")
+        self._check_tables()
+        t = bs.Tables.of(self)
+        sym = symbols.detach().to(torch.int32).cpu().contiguous().numpy()
+        idx = indexes.detach().to(torch.int32).cpu().contiguous().numpy()
+        return [bs.encode(sym[i], idx[i], t) for i in range(sym.shape[0])]
+
+    def decompress(self, strings, indexes, means=None, flag=1):
+        """entropy_models.py:244-294."""
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError("Invalid `strings` parameter type.")
+        if not len(strings) == indexes.size(0):
+            raise ValueError("Invalid strings or indexes parameters")
+        if len(indexes.size()) < 2:
+            raise ValueError("Invalid `indexes` size. Expected a tensor with at least 2 dimensions.")
+        self._check_tables()
+        if means is not None:
+            if means.size()[:2] != indexes.size()[:2]:
+                raise ValueError("Invalid means or indexes parameters")
+            if means.size() != indexes.size():
+                for i in range(2, len(indexes.size())):
+                    if means.size(i) != 1:
+                        raise ValueError("Invalid means parameters")
+        t = bs.Tables.of(self)
+        idx = indexes.detach().to(torch.int32).cpu().contiguous().numpy()
+        out = np.stack([bs.decode(s, idx[i], t).reshape(idx[i].shape) for i, s in enumerate(strings)])
+        outputs = torch.from_numpy(out).to(indexes.device)
+        return self.dequantize(outputs, means)
 
 
 def _ones_like(v: ops.View) -> ops.View:
@@ -138,10 +188,60 @@ class EntropyBottleneck(EntropyModel):
         return zhat.torch_nchw(), lik.torch_nchw()
 
     def loss(self):
-        raise NotImplementedError("aux loss needs autograd through the factorised prior; not built yet")
-
-    def update(self, force: bool = False):
         raise NotImplementedError(_NOT_BUILT)
+
+    def _logits_cumulative_host(self, v):
+        """entropy_models.py:403-422 on the host (table building only; the per-pixel likelihood is
+        vam_eb_forward)."""
+        logits = v
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(F.softplus(getattr(self, f"_matrix{i:d}").detach().cpu()), logits)
+            logits = logits + getattr(self, f"_bias{i:d}").detach().cpu()
+            if i < len(self.filters):
+                logits = logits + torch.tanh(getattr(self, f"_factor{i:d}").detach().cpu()) * torch.tanh(logits)
+        return logits
+
+    def update(self, force: bool = False) -> bool:
+        """entropy_models.py:358-396: per-channel CDF tables from the learned quantiles."""
+        q = self.quantiles.detach().cpu()
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+        dev = self._offset.device
+        self._offset = (-minima).to(dev)
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative_host(samples - 0.5)
+        upper = self._logits_cumulative_host(samples + 0.5)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+        return True
+
+    @staticmethod
+    def _build_indexes(size):
+        N, C_ = size[0], size[1]
+        view = [1] * len(size)
+        view[1] = -1
+        return torch.arange(C_, dtype=torch.int32).view(*view).repeat(N, 1, *size[2:])
+
+    def compress(self, x):
+        """entropy_models.py:511-518."""
+        indexes = self._build_indexes(x.size()).to(x.device)
+        medians = self._get_medians().detach().reshape(1, -1, *([1] * (x.dim() - 2))).expand_as(x)
+        return super().compress(x, indexes, medians)
+
+    def decompress(self, strings, size):
+        """entropy_models.py:520-525."""
+        out_size = (len(strings), self._quantized_cdf.size(0), *size)
+        dev = self.quantiles.device
+        indexes = self._build_indexes(out_size).to(dev)
+        medians = self._get_medians().detach().reshape(1, -1, *([1] * len(size))).expand(out_size)
+        return super().decompress(strings, indexes, medians)
 
 
 class GaussianConditional(EntropyModel):
@@ -168,13 +268,33 @@ class GaussianConditional(EntropyModel):
         return torch.Tensor(tuple(float(s) for s in scale_table))
 
     def update_scale_table(self, scale_table):
-        """entropy_models.py:582-589 without the CDF rebuild (that is the bitstream layer)."""
-        device = self.scale_table.device
-        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        """entropy_models.py:582-589."""
+        self.update(scale_table)
         return True
 
+    @staticmethod
+    def _standardized_cumulative(inputs):
+        return 0.5 * torch.erfc(float(-(2 ** -0.5)) * inputs)
+
     def update(self, scale_table):
-        raise NotImplementedError(_NOT_BUILT)
+        """entropy_models.py:591-618: one CDF table per entry of the scale table."""
+        dev = self.scale_table.device
+        table = self._prepare_scale_table([float(s) for s in scale_table])
+        multiplier = -scipy.stats.norm.ppf(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(torch.max(pmf_length).item())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        scale = table.unsqueeze(1).float()
+        upper = self._standardized_cumulative((0.5 - samples) / scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        self.scale_table = table.to(dev)
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._offset = (-pmf_center).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+        return True
 
     def forward(self, inputs, scales, means=None, training=None, mask=None):
         """Eval forward (entropy_models.py:637-652): (round(x-mu)+mu, likelihood)."""

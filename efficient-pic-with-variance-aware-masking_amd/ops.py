@@ -270,29 +270,59 @@ def variance_mask(sigma: View, pr: float, mask: View, n_slice: int = 1, slice_C:
                                        thr.data_ptr() if thr is not None else None, stream_ptr()), "vam_variance_mask")
 
 
+@dataclass
+class IView:
+    """int32 NHWC channel window (symbols / table indexes)."""
+    buf: torch.Tensor   # [B,H,W,ld] int32
+    c0: int
+    C: int
+
+    @property
+    def ptr(self): return self.buf.data_ptr() + 4 * self.c0
+    @property
+    def ld(self): return self.buf.shape[3]
+
+    def window(self, c0, C_): return IView(self.buf, self.c0 + c0, C_)
+
+
+def new_iview(B, H, W, C_, device="cuda") -> IView:
+    return IView(torch.empty((B, H, W, C_), dtype=torch.int32, device=device), 0, C_)
+
+
 def gauss_tail(y: View, mu: View, sigma: View, *, y2: Optional[View] = None, mask: Optional[View] = None,
-               yhat: Optional[View] = None, lik: Optional[View] = None, sym: Optional[torch.Tensor] = None,
+               yhat: Optional[View] = None, lik: Optional[View] = None, sym=None,
                log2sum: Optional[torch.Tensor] = None):
     n_pix = y.n_pix
     def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
-    sym_ptr, sym_ld = (sym.data_ptr(), sym.shape[-1]) if sym is not None else (None, 0)
+    if sym is None:
+        sym_ptr, sym_ld = None, 0
+    elif isinstance(sym, IView):
+        sym_ptr, sym_ld = sym.ptr, sym.ld
+    else:
+        sym_ptr, sym_ld = sym.data_ptr(), sym.shape[-1]
     L.check(L.load().vam_gauss_tail(*p(y), *p(y2), *p(mu), *p(sigma), *p(mask), *p(yhat), *p(lik), sym_ptr, sym_ld,
                                     log2sum.data_ptr() if log2sum is not None else None, y.H * y.W, n_pix, y.C,
                                     stream_ptr()), "vam_gauss_tail")
 
 
-def build_indexes(sigma: View, table: torch.Tensor, mask: Optional[View] = None) -> torch.Tensor:
-    idx = torch.empty((sigma.B, sigma.H, sigma.W, sigma.C), dtype=torch.int32, device=sigma.buf.device)
+def build_indexes(sigma: View, table: torch.Tensor, mask: Optional[View] = None, out: Optional[IView] = None) -> torch.Tensor:
+    if out is None:
+        out = new_iview(sigma.B, sigma.H, sigma.W, sigma.C, sigma.buf.device)
     L.check(L.load().vam_build_indexes(sigma.ptr, sigma.ld, mask.ptr if mask is not None else None,
                                        mask.ld if mask is not None else 0, table.data_ptr(), table.numel(),
-                                       idx.data_ptr(), sigma.C, sigma.n_pix, sigma.C, stream_ptr()), "vam_build_indexes")
-    return idx
+                                       out.ptr, out.ld, sigma.n_pix, sigma.C, stream_ptr()), "vam_build_indexes")
+    return out.buf
+
+
+def dequantize(sym: IView, mu: Optional[View], out: View):
+    L.check(L.load().vam_dequantize(sym.ptr, sym.ld, mu.ptr if mu is not None else None, mu.ld if mu is not None else 0,
+                                    out.ptr, out.ld, out.n_pix, out.C, stream_ptr()), "vam_dequantize")
 
 
 def eb_forward(z: View, params: torch.Tensor, zhat: Optional[View], lik: Optional[View],
-               log2sum: Optional[torch.Tensor] = None):
+               log2sum: Optional[torch.Tensor] = None, sym: Optional[IView] = None):
     def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
-    L.check(L.load().vam_eb_forward(z.ptr, z.ld, params.data_ptr(), z.C, *p(zhat), *p(lik),
+    L.check(L.load().vam_eb_forward(z.ptr, z.ld, params.data_ptr(), z.C, *p(zhat), *p(lik), *p(sym),
                                     log2sum.data_ptr() if log2sum is not None else None, z.H * z.W, z.n_pix,
                                     stream_ptr()), "vam_eb_forward")
 

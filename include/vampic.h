@@ -183,12 +183,15 @@ int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int l
                       long n_pix, int C, void* stream);
 
 /* EntropyBottleneck eval forward (entropy_models.py:403-436,449-492) on z NHWC [n_pix, C]:
- * zhat = round(z-med)+med ; lik = |sigmoid(s*upper)-sigmoid(s*lower)| clamped at 1e-9.
+ * zhat = round(z-med)+med ; sym (may be NULL) = round(z-med) ; lik = |sigmoid(s*upper)-sigmoid(s*lower)| clamped at 1e-9.
  * params: the 15 tensors _matrix0.._4,_bias0.._4,_factor0.._3 and quantiles as stored in the
  * state_dict, concatenated per tensor (see INTEGRATION.md for the order), C channels. */
 int vam_eb_forward(const float* z, int ld_z, const float* params, int C,
-                   float* zhat, int ld_zhat, float* lik, int ld_lik,
+                   float* zhat, int ld_zhat, float* lik, int ld_lik, int32_t* sym, int ld_sym,
                    double* log2sum, int pix_per_item, long n_pix, void* stream);
+/* EntropyModel.dequantize (entropy_models.py:161-168): out = float(sym) + mu (mu may be NULL). */
+int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, float* out, int ld_out,
+                   long n_pix, int C, void* stream);
 
 /* out[p, c] = a[p, c] + b[p, c]   (channel windows) — mu_total = mu + yhat_base (pic.py:603) */
 int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out,
@@ -197,6 +200,22 @@ int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int 
 int vam_memset_zero(void* ptr, size_t bytes, void* stream);
 /* sum((a-b)^2) accumulated in double into acc[0] (PSNR, utility/functions.py:172-174) */
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
+
+/* ------------------------------------------------------------------ bitstream (HOST pointers) */
+/* compressai `_CXX.pmf_to_quantized_cdf` (reference entropy_models.py:61-64): n probabilities ->
+ * n+1 cumulative counts at `precision` bits, every symbol given a non-zero frequency. */
+int vam_pmf_to_quantized_cdf(const float* pmf_host, int n, int precision, int32_t* cdf_out_host);
+/* compressai `ans.RansEncoder.encode_with_indexes` / `RansDecoder.decode_with_indexes`
+ * (reference entropy_models.py:231-239,280-290): symbols[i] coded with table indexes[i];
+ * cdfs is [n_cdfs][cdf_stride], cdf_sizes[k] = valid entries of table k (pmf length + 2), offsets[k]
+ * = symbol value of entry 0; out-of-range symbols use 4-bit bypass chunks.  16-bit precision.
+ * encode returns the stream length in bytes (<0 on error). */
+long vam_rans_encode(const int32_t* symbols_host, const int32_t* indexes_host, long n, const int32_t* cdfs_host,
+                     int cdf_stride, const int32_t* cdf_sizes_host, const int32_t* offsets_host, int n_cdfs,
+                     uint8_t* out_host, long out_capacity);
+int vam_rans_decode(const uint8_t* in_host, long n_bytes, const int32_t* indexes_host, long n,
+                    const int32_t* cdfs_host, int cdf_stride, const int32_t* cdf_sizes_host,
+                    const int32_t* offsets_host, int n_cdfs, int32_t* symbols_out_host);
 
 /* ------------------------------------------------------------------ graphs / timing */
 int vam_graph_begin(void* stream);

@@ -199,3 +199,26 @@ def test_errors_are_loud():
     with pytest.raises(Exception):
         ops.conv_problem(m.cuda().packed(), [ops.from_nchw(torch.randn(1, 4, 4, 4, device="cuda"))],
                          ops.new_view(1, 4, 4, 8))   # channel mismatch
+
+
+def test_conv_result_is_independent_of_tiling():
+    """Encoder and decoder run the same layers under different groupings / tile shapes; the K
+    order is canonical, so every (BM, BN, BK) must give bit-identical outputs."""
+    lib = L.load()
+    for cin, n, k, st, hw in ((192, 192, 3, 1, (16, 16)), (176, 128, 3, 1, (16, 16)), (512, 224, 3, 1, (16, 16)),
+                              (192, 192, 5, 2, (32, 32)), (96, 192, 1, 1, (16, 16))):
+        m = Ly.Conv2d(cin, n, k, st).cuda()
+        _fill(m, 21)
+        x = _rand((4, cin) + hw, 22).cuda()
+        outs = []
+        for bm, bn, bk in ((0, 0, 0), (64, 64, 16), (64, 64, 32), (128, 64, 16), (128, 192, 16), (64, 128, 32), (128, 32, 16)):
+            if bk == 32 and cin % 32:
+                continue
+            lib.vam_conv_force_tile(bm, bn, bk)
+            try:
+                with torch.no_grad():
+                    outs.append(m(x).clone())
+            finally:
+                lib.vam_conv_force_tile(0, 0, 0)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (cin, n, k, st)
