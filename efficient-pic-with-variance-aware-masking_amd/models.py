@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -86,7 +87,12 @@ class CompressionModel(nn.Module):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
 
     def update(self, force=False):
-        raise NotImplementedError(_NOT_BUILT)
+        """models/base.py:41-60."""
+        updated = False
+        for m in self.children():
+            if isinstance(m, EntropyBottleneck):
+                updated |= m.update(force=force)
+        return updated
 
 
 def _resize_cdf_buffers(module, prefix, names, state_dict):
@@ -136,6 +142,7 @@ class VarianceMaskingPIC(CompressionModel):
         self.cc_scale_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1)) for i in range(np_))
         self.lrp_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 2, sp1 + 1)) for i in range(nb))
         self._plans: Dict[tuple, "_FsqPlan"] = {}
+        self._dec_plans: Dict[tuple, "_DecPlan"] = {}
         self.use_graph = True
 
     # ---- reference helpers kept for the harness
@@ -166,10 +173,13 @@ class VarianceMaskingPIC(CompressionModel):
         return tr
 
     def update(self, scale_table=None, force=True):
-        """Sets the scale table (needed by build_indexes); the CDF tables are the bitstream layer."""
+        """models/pic.py:230-237: scale table + CDF tables of both entropy models."""
         if scale_table is None:
             scale_table = get_scale_table()
         self.gaussian_conditional.update_scale_table([float(s) for s in scale_table])
+        self.entropy_bottleneck.update(force=force)
+        self._plans.clear()
+        self._dec_plans.clear()
         return True
 
     def load_state_dict(self, state_dict, strict=True):
@@ -178,10 +188,12 @@ class VarianceMaskingPIC(CompressionModel):
         _resize_cdf_buffers(self.entropy_bottleneck, "entropy_bottleneck",
                             ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
         self._plans.clear()
+        self._dec_plans.clear()
         return nn.Module.load_state_dict(self, state_dict, strict=strict)
 
     def _apply(self, fn, *a, **k):
         self._plans.clear()
+        self._dec_plans.clear()
         return super()._apply(fn, *a, **k)
 
     def define_quality(self, quality):
@@ -223,14 +235,14 @@ class VarianceMaskingPIC(CompressionModel):
                                       "(dual encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable, "
                                       "dim_chunk 32, division [d, 2d], 5 support slices)")
 
-    def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None) -> "_FsqPlan":
+    def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False) -> "_FsqPlan":
         B, C_, H, W = x.shape
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
-        key = (B, H, W, base_only, rem_idx, str(x.device))
+        key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ())
         p = self._plans.get(key)
         if p is None:
-            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device)
+            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols)
             self._plans[key] = p
         return p
 
@@ -269,11 +281,72 @@ class VarianceMaskingPIC(CompressionModel):
                                 "z": base["likelihoods"]["z"]},
                 "y_hat": y_hat_total, "y_base": base["y_hat"], "y_prog": out["y_hat"] if out else base["y_hat"]}
 
-    def compress(self, *a, **k):
-        raise NotImplementedError(_NOT_BUILT)
+    # ---- bitstream path (models/pic.py:671-967; rem_pic.py:425-818)
+    def _rem_choice(self, quality, checkpoint_rep):
+        return None                                    # no REM in the plain model
 
-    def decompress(self, *a, **k):
-        raise NotImplementedError(_NOT_BUILT)
+    def compress(self, x, quality=0.0, mask_pol=None, checkpoint_rep=None, real_compress=True):
+        """One rANS stream per (slice, image) for y and per image for z.  The latents, entropy
+        parameters, masks, symbols and table indexes come from the fused HIP plan; only the
+        bit-serial coder runs on the host (as in the reference, entropy_models.py:231-239)."""
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        Ly._no_autograd(x)
+        L.require_gpu()
+        self._check_config()
+        base_only = quality <= 0
+        rem_idx = None if base_only else self._rem_choice(quality, checkpoint_rep)
+        pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
+        plan = self._plan(x, base_only=base_only, rem_idx=rem_idx, symbols=True)
+        out = plan.execute(x, pr, checkpoint_rep if rem_idx is not None else None, self.use_graph, True)
+        B, C = plan.B, self.dim_chunk
+        n_sl = self.ns0 if base_only else self.ns1
+        y_strings: List[List[bytes]] = []
+        if real_compress:
+            from . import bitstream as bs
+            tg, te = bs.Tables.of(self.gaussian_conditional), bs.Tables.of(self.entropy_bottleneck)
+            sym = plan.sym.buf.cpu().numpy()           # [B,h,w,C_lat] int32 (synchronises)
+            idx = plan.idx.buf.cpu().numpy()
+            zs = plan.z_sym.buf.cpu().numpy()
+            for i in range(n_sl):                       # stream order: [C, h, w] per image, as the reference flattens
+                sl = slice(i * C, (i + 1) * C)
+                y_strings.append([bs.encode(sym[b, :, :, sl].transpose(2, 0, 1), idx[b, :, :, sl].transpose(2, 0, 1), tg)
+                                  for b in range(B)])
+            zi = torch.arange(self.N, dtype=torch.int32).numpy()[:, None, None]
+            z_strings = [bs.encode(zs[b].transpose(2, 0, 1), np.broadcast_to(zi, (self.N,) + zs.shape[1:3]), te)
+                         for b in range(B)]
+        else:                                           # rem_pic.py:498-500,594-597: the quantised tensors instead of bytes
+            sy = plan.sym.buf.permute(0, 3, 1, 2)
+            y_strings = [sy[:, i * C:(i + 1) * C].float() for i in range(n_sl)]
+            z_strings = [plan.z_sym.buf.permute(0, 3, 1, 2).float()]
+        res = {"strings": [y_strings, z_strings], "shape": (plan.H // 64, plan.W // 64),
+               "masks": [] if base_only else list(out["mask"].chunk(self.ns0, 1)), "y_hat": out["y_hat"]}
+        if base_only:
+            res.update({"mean_base": out["mu_base"], "scale_base": out["std_base"], "std_base": out["std_base"],
+                        "y_hat_base": out["y_hat"]})
+        return res
+
+    def decompress(self, strings, shape, quality, mask_pol=None, checkpoint_rep=None):
+        """models/pic.py:838-967: z -> hyper-synthesis -> slice by slice (entropy parameters on the
+        GPU, rANS decode on the host, LRP on the GPU) -> g_s."""
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        L.require_gpu()
+        self._check_config()
+        dev = self.entropy_bottleneck.quantiles.device
+        B = len(strings[1])
+        hz, wz = int(shape[0]), int(shape[1])
+        base_only = quality == 0
+        rem_idx = None if base_only else self._rem_choice(quality, checkpoint_rep)
+        key = (B, hz, wz, base_only, rem_idx, str(dev))
+        dp = self._dec_plans.get(key)
+        if dp is None:
+            dp = _DecPlan(self, B, hz, wz, base_only, rem_idx, dev)
+            self._dec_plans[key] = dp
+        pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
+        return {"x_hat": dp.decode(strings, pr, checkpoint_rep if rem_idx is not None else None)}
 
 
 class VarianceMaskingPICREM(VarianceMaskingPIC):
@@ -361,29 +434,35 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         self._check_config()
         if not self.mu_std:
             raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
-        rem_idx = None
-        if quality != 0 and checkpoint_ref is not None and quality > self.check_levels[0]:
-            _, _, right = self.find_check_quality(quality)
-            if self.enable_rem[right]:
-                rem_idx = self._rem_index(quality)
+        rem_idx = self._rem_choice(quality, checkpoint_ref) if quality != 0 else None
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
         plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
         return plan.execute(x, pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, clone)
 
+    def _rem_choice(self, quality, checkpoint_rep):
+        """Which REM (if any) refines the entropy parameters (rem_pic.py:197-213,363,566)."""
+        if checkpoint_rep is None or quality <= self.check_levels[0]:
+            return None
+        _, _, right = self.find_check_quality(quality)
+        return self._rem_index(quality) if self.enable_rem[right] else None
+
     def ExtractChekpointRepr(self, x, quality, rc=True, y_check=None):
-        """rem_pic.py:121-132 returns compress(...)["y_hat"]; with a lossless coder that is the
-        likelihood path's y_hat at the same quality, which is what the plan computes
-        (the host rANS detour of the reference is not needed for this tensor)."""
-        return self.forward(x, quality=quality, training=False, checkpoint_ref=y_check)["y_hat"]
+        """rem_pic.py:121-132: compress(...)["y_hat"].  The coder is lossless, so y_hat does not
+        depend on ``rc``; with rc=False no host coding happens at all."""
+        if rc and self.gaussian_conditional._quantized_cdf.numel() == 0:
+            rc = False                                 # tables not built: y_hat is the same without the bytes
+        return self.compress(x, quality=quality, mask_pol="point-based-std", real_compress=rc,
+                             checkpoint_rep=y_check)["y_hat"]
 
 
 # ----------------------------------------------------------------------------- the fused plan
 class _FsqPlan:
     """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
 
-    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device):
+    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False):
         self.m, self.B, self.H, self.W = m, B, H, W
         self.base_only, self.rem_idx = base_only, rem_idx
+        self.symbols = symbols
         self.pr = 0.0
         self.graphs: Dict[float, ops.Graph] = {}
         self.stream = None
@@ -411,7 +490,9 @@ class _FsqPlan:
         E.lower_stacks(plan, [m.h_a], [[y]], [z])
         self.z_hat = plan.buf(B, h // 4, w // 4, m.N)
         self.z_lik = plan.buf(B, h // 4, w // 4, m.N)
-        plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z))
+        self.z_sym = ops.new_iview(B, h // 4, w // 4, m.N, device) if symbols else None
+        plan.keep.append(self.z_sym)
+        plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z, sym=self.z_sym))
         nh = 1 if base_only else 2
         means_h = plan.buf(B, h, w, nh * d)
         scales_h = plan.buf(B, h, w, nh * d)
@@ -426,6 +507,13 @@ class _FsqPlan:
         self.mu_b = plan.buf(B, h, w, d)
         self.std_b = plan.buf(B, h, w, d)
         self.lik = plan.buf(B, h, w, d if base_only else 2 * d)
+        # entropy-coder inputs (compress only): quantised symbols and scale-table indexes
+        self.sym = ops.new_iview(B, h, w, d if base_only else 2 * d, device) if symbols else None
+        self.idx = ops.new_iview(B, h, w, d if base_only else 2 * d, device) if symbols else None
+        plan.keep += [self.sym, self.idx]
+        table = m.gaussian_conditional.scale_table
+        if symbols and table.numel() == 0:
+            raise ValueError("empty scale table: call model.update() before compress()")
         sl = lambda v, i, n=1: v.window(i * C, n * C)
         mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
 
@@ -436,7 +524,10 @@ class _FsqPlan:
                            [sl(self.mu_b, i) for i in idx] + [sl(self.std_b, i) for i in idx])
             i0, n = idx[0], len(idx)
             plan.call(lambda: ops.gauss_tail(sl(y, i0, n), sl(self.mu_b, i0, n), sl(self.std_b, i0, n),
-                                             yhat=sl(yq, i0, n), lik=sl(self.lik, i0, n), log2sum=ls_y))
+                                             yhat=sl(yq, i0, n), lik=sl(self.lik, i0, n), log2sum=ls_y,
+                                             sym=sl(self.sym, i0, n) if symbols else None))
+            if symbols:                                                               # pic.py:737
+                plan.call(lambda: ops.build_indexes(sl(self.std_b, i0, n), table, out=sl(self.idx, i0, n)))
             E.lower_stacks(plan, [m.lrp_transforms[i] for i in idx], [[mh0] + sup + [sl(yq, i)] for i in idx],
                            [sl(yb, i) for i in idx],
                            [dict(act=L.ACT_HALF_TANH, post=sl(yq, i)) for i in idx])
@@ -499,7 +590,10 @@ class _FsqPlan:
         plan.call(lambda: ops.variance_mask(std_f, self.pr, self.mask, n_slice=ns, thr=self.thr))   # pic.py:621-622
         rq = plan.buf(B, h, w, d)
         plan.call(lambda: ops.gauss_tail(y.window(d, d), mu_f, std_f, y2=y.window(0, d), mask=self.mask, yhat=rq,
-                                         lik=self.lik.window(d, d), log2sum=ls_y))                  # pic.py:625-629
+                                         lik=self.lik.window(d, d), log2sum=ls_y,
+                                         sym=self.sym.window(d, d) if symbols else None))           # pic.py:625-629
+        if symbols:                                                                   # pic.py:813
+            plan.call(lambda: ops.build_indexes(std_f, table, mask=self.mask, out=self.idx.window(d, d)))
         yp = self.y_prog = plan.buf(B, h, w, d)
         E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
                        [sl(yp, j) for j in range(ns)],
@@ -549,6 +643,135 @@ class _FsqPlan:
                         "mu": nchw(self.mu_f), "std_base": nchw(self.std_b), "std": nchw(self.std_f),
                         "mask": nchw(self.mask)})
         return out
+
+
+class _DecPlan:
+    """``decompress`` for one (B, z-shape): the same kernels as the encoder's plan, cut where the
+    host rANS decoder has to deliver the symbols of a slice (models/pic.py:862-960).  The conv
+    kernel's K order is canonical, so mu / sigma / masks / indexes are bit-identical to the
+    encoder's although the launches are grouped differently."""
+
+    def __init__(self, m: VarianceMaskingPIC, B, hz, wz, base_only, rem_idx, device):
+        self.m, self.B, self.base_only, self.rem_idx = m, B, base_only, rem_idx
+        self.device = torch.device(device)
+        self.pr = 0.0
+        self.stream = None
+        h, w = hz * 4, wz * 4
+        self.h, self.w, self.hz, self.wz = h, w, hz, wz
+        d, C, ns = m.division_dimension[0], m.dim_chunk, m.ns0
+        f32 = dict(dtype=torch.float32, device=device)
+        table = m.gaussian_conditional.scale_table
+        if table.numel() == 0:
+            raise ValueError("empty scale table: call model.update() before decompress()")
+        nv, ni = (lambda c, hh=h, ww=w: ops.new_view(B, hh, ww, c, device)), (lambda c, hh=h, ww=w: ops.new_iview(B, hh, ww, c, device))
+        sl = lambda v, i, n=1: v.window(i * C, n * C)
+        self.x_hat = torch.empty((B, 3, h * 16, w * 16), **f32)
+        # ---- z
+        self.z_sym = ni(m.N, hz, wz)
+        med = nv(m.N, hz, wz)
+        med.buf.copy_(m.entropy_bottleneck._get_medians().detach().reshape(1, 1, 1, -1).expand_as(med.buf))
+        z_hat = nv(m.N, hz, wz)
+        nh = 1 if base_only else 2
+        means_h, scales_h = nv(nh * d), nv(nh * d)
+        P = self.p_hyper = E.Plan(device)
+        P.call(lambda: ops.dequantize(self.z_sym, med, z_hat))                       # entropy_models.py:520-525
+        E.lower_stacks(P, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)], [[z_hat]] * (2 * nh),
+                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
+        # ---- base slices
+        mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
+        yq, yb, mu_b, std_b = nv(d), nv(d), nv(d), nv(d)
+        self.idx_b, self.sym_b = ni(d), ni(d)
+        self.mu_b, self.std_b = mu_b, std_b
+        self.p_base = []
+        for i in range(ns):
+            sup = [sl(yb, 0, min(m.max_support_slices, i))] if i > 0 else []
+            Pa, Pb = E.Plan(device), E.Plan(device)
+            E.lower_stacks(Pa, [m.cc_mean_transforms[i], m.cc_scale_transforms[i]], [[mh0] + sup, [sh0] + sup],
+                           [sl(mu_b, i), sl(std_b, i)])
+            Pa.call(lambda i=i: ops.build_indexes(sl(std_b, i), table, out=sl(self.idx_b, i)))          # pic.py:879
+            Pb.call(lambda i=i: ops.dequantize(sl(self.sym_b, i), sl(mu_b, i), sl(yq, i)))               # pic.py:884
+            E.lower_stacks(Pb, [m.lrp_transforms[i]], [[mh0] + sup + [sl(yq, i)]], [sl(yb, i)],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i))])
+            self.p_base.append((Pa, Pb))
+        self.p_syn = E.Plan(device)
+        if base_only:
+            E.lower_g_s(self.p_syn, [m.g_s[0]], [yb], [self.x_hat])
+            return
+        # ---- progressive slices
+        mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
+        mu_p, std_p, mu_tot, mask, rq, yp = nv(d), nv(d), nv(d), nv(d), nv(d), nv(d)
+        mu_f, std_f = (nv(d), nv(d)) if rem_idx is not None else (mu_p, std_p)
+        self.ck = nv(d) if rem_idx is not None else None
+        att = nv(d) if rem_idx is not None else None
+        self.idx_p, self.sym_p = ni(d), ni(d)
+        sp = m.support_progressive_slices
+        self.p_prog = []
+        for j in range(ns):
+            s_ = min(sp, j)
+            ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s_, s_)] if s_ else [])
+            ss = [sh1, sl(yb, j)] + ([sl(std_p, j - s_, s_)] if s_ else [])
+            Pa, Pb = E.Plan(device), E.Plan(device)
+            E.lower_stacks(Pa, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss], [sl(mu_p, j), sl(std_p, j)])
+            Pa.call(lambda j=j: ops.add(sl(mu_p, j), sl(yb, j), sl(mu_tot, j)))
+            if rem_idx is not None:
+                Pa.call(lambda j=j: ops.variance_mask(sl(std_p, j), self.pr, sl(att, j), n_slice=1))
+                E.lower_rem_blocks(Pa, [m.post_latent[rem_idx][j]], [sl(self.ck, j)], [[sl(mu_b, j), sl(std_b, j)]],
+                                   [[sl(mu_p, j), sl(std_p, j)]], [sl(att, j)], [[sl(mu_f, j), sl(std_f, j)]])
+            Pa.call(lambda j=j: ops.variance_mask(sl(std_f, j), self.pr, sl(mask, j), n_slice=1))       # pic.py:942
+            Pa.call(lambda j=j: ops.build_indexes(sl(std_f, j), table, mask=sl(mask, j), out=sl(self.idx_p, j)))  # :945
+            Pb.call(lambda j=j: ops.dequantize(sl(self.sym_p, j), sl(mu_f, j), sl(rq, j)))               # :948
+            E.lower_stacks(Pb, [m.lrp_transforms_prog[j]], [ms + [sl(rq, j)]], [sl(yp, j)],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))])
+            self.p_prog.append((Pa, Pb))
+        E.lower_g_s(self.p_syn, [m.g_s[1]], [yp], [self.x_hat])
+
+    def _decode_slice(self, strings, idx_view: ops.IView, sym_view: ops.IView, tables, C):
+        """indexes GPU -> host, rANS decode per image, symbols host -> GPU (NHWC window)."""
+        from . import bitstream as bs
+        B, h, w = self.B, idx_view.buf.shape[1], idx_view.buf.shape[2]
+        self.stream.synchronize()
+        idx = idx_view.buf[..., idx_view.c0:idx_view.c0 + C].cpu().numpy()          # [B,h,w,C]
+        out = np.empty((B, h, w, C), dtype=np.int32)
+        for b in range(B):
+            dec = bs.decode(strings[b], idx[b].transpose(2, 0, 1), tables)           # stream order [C,h,w]
+            out[b] = dec.reshape(C, h, w).transpose(1, 2, 0)
+        sym_view.buf[..., sym_view.c0:sym_view.c0 + C].copy_(torch.from_numpy(out).to(self.device))
+
+    def decode(self, strings, pr, checkpoint_rep):
+        from . import bitstream as bs
+        m = self.m
+        self.pr = float(pr)
+        y_strings, z_strings = strings[0], strings[1]
+        n_need = m.ns0 if self.base_only else m.ns1
+        if len(y_strings) < n_need or len(z_strings) != self.B:
+            raise ValueError(f"expected {n_need} slice streams x {self.B} images, got {len(y_strings)} x {len(z_strings)}")
+        tg, te = bs.Tables.of(m.gaussian_conditional), bs.Tables.of(m.entropy_bottleneck)
+        cur = torch.cuda.current_stream(self.device)
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
+        self.stream.wait_stream(cur)
+        C = m.dim_chunk
+        with torch.cuda.stream(self.stream):
+            if checkpoint_rep is not None:
+                ck = ops.from_nchw(checkpoint_rep.to(self.device))
+                self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])
+            zi = np.broadcast_to(np.arange(m.N, dtype=np.int32)[:, None, None], (m.N, self.hz, self.wz))
+            zs = np.stack([bs.decode(z_strings[b], zi, te).reshape(m.N, self.hz, self.wz).transpose(1, 2, 0)
+                           for b in range(self.B)])
+            self.z_sym.buf.copy_(torch.from_numpy(zs).to(self.device))
+            self.p_hyper.run()
+            for i, (Pa, Pb) in enumerate(self.p_base):
+                Pa.run()
+                self._decode_slice(y_strings[i], self.idx_b.window(i * C, C), self.sym_b.window(i * C, C), tg, C)
+                Pb.run()
+            if not self.base_only:
+                for j, (Pa, Pb) in enumerate(self.p_prog):
+                    Pa.run()
+                    self._decode_slice(y_strings[m.ns0 + j], self.idx_p.window(j * C, C), self.sym_p.window(j * C, C), tg, C)
+                    Pb.run()
+            self.p_syn.run()
+        cur.wait_stream(self.stream)
+        return self.x_hat.clone()
 
 
 models = {"pic": VarianceMaskingPIC, "rem": VarianceMaskingPICREM}
