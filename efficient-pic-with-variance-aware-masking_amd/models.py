@@ -439,6 +439,23 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
         return plan.execute(x, pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, clone)
 
+    def apply_latent_enhancement(self, current_index, quality, quality_bar, y_b_hat, mu_scale_base, mu_scale_enh,
+                                 mu, scale, training=False, mask_pol="point-based-std", attention_mask=None):
+        """models/rem_pic.py:167-220 on NCHW tensors (module-level surface used by the progressive
+        harness, test/functions_encode.py:126-141): refine (mu, scale) of one progressive slice."""
+        if attention_mask is None:
+            attention_mask = self.masking(scale, pr=quality, mask_pol=mask_pol)
+        if self.mu_std:
+            attention_mask = torch.cat([attention_mask, attention_mask], dim=1)
+        if quality <= self.check_levels[0]:
+            return mu, scale
+        block = self.post_latent[self._rem_index(quality)][current_index]
+        enhanced = block(y_b_hat, mu_scale_base, mu_scale_enh, attention_mask)
+        if self.mu_std:
+            mu, scale = enhanced.chunk(2, 1)
+            return mu, scale
+        return mu, enhanced
+
     def _rem_choice(self, quality, checkpoint_rep):
         """Which REM (if any) refines the entropy parameters (rem_pic.py:197-213,363,566)."""
         if checkpoint_rep is None or quality <= self.check_levels[0]:

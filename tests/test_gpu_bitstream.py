@@ -92,3 +92,29 @@ def test_corrupt_stream_is_detected_or_changes_output(codec):
         strings[0][3][0] = strings[0][3][0][:8]                  # truncate one slice stream
         with pytest.raises(vampic._lib.VamError):
             codec.decompress(strings, enc["shape"], quality=2.5)
+
+
+def test_progressive_container_layers(codec):
+    """Single progressive bitstream (reference src/test/functions_encode.py / functions_decode.py): decoding
+    the first k layers must reconstruct what forward_single_quality(q_list[k-1]) reconstructs — the layers
+    are exactly the latents the variance mask adds between consecutive qualities."""
+    from vampic import progressive as P
+    net = codec
+    x = synth.synth_image(1, 64, 64, seed=9).cuda()
+    q_list = [0.5, 1, 2.5, 5]
+    bit, (bz, bb, bl) = P.encode(net, x, q_list=q_list)
+    assert set(bit) == {"q_list", "shape", "z", "base", "progressive"} and len(bit["progressive"]) == len(q_list)
+    assert bz > 0 and bb > 0 and all(b > 0 for b in bl)
+    with torch.no_grad():
+        d0 = P.decode(net, bit, q_ind=0)
+        fw0 = net.forward_single_quality(x, 0)
+        assert (d0["x_hat"] - fw0["x_hat"]).abs().max().item() <= 1e-5
+        state = {}
+        for k in range(1, len(q_list) + 1):
+            dk = P.decode(net, bit, q_ind=k, z_data=state.get("z"), res_base=d0["res_base"], entropy_data=state.get("e"))
+            state = {"z": dk["z_data"], "e": dk["entropy_data"]}
+            fw = net.forward_single_quality(x, q_list[k - 1])
+            # same latents: every symbol of the masked residual agrees (LRP / synthesis are float ops
+            # evaluated through differently shaped launches, hence the 1e-5)
+            assert (dk["y_prog"] - fw["y_hat"]).abs().max().item() <= 1e-4
+            assert (dk["x_hat"].clamp(0, 1) - fw["x_hat"]).abs().max().item() <= 1e-5
