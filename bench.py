@@ -85,12 +85,20 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL ("nccl") over xGMI on the 8-GPU node.  VAMPIC_DIST_BACKEND=gloo is for rehearsing the
+        # multi-rank code path on a one-GPU box (all ranks then share cuda:0; RCCL refuses duplicate GPUs).
+        backend = os.environ.get("VAMPIC_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            torch.cuda.set_device(local % ndev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
+    red_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
     import vampic
     from vampic import ops
@@ -115,7 +123,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
     from vampic import sharding
-    dt = sharding.max_over_ranks(dt, dev)                     # slowest rank (RCCL all-reduce MAX)
+    dt = sharding.max_over_ranks(dt, red_dev)                 # slowest rank (RCCL all-reduce MAX)
     ms_step = dt / a.steps * 1e3
     mp_s = sharding.whole_job_megapixels_per_s(B, H, W, a.steps, world, dt)
 
