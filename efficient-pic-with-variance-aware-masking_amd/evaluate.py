@@ -1,0 +1,100 @@
+"""Evaluation drivers and metric helpers (inference half): the counterparts of
+``test_epoch`` / ``compress_with_ac`` (reference training/step.py:206-243,259-358) and of
+``compute_psnr`` / ``compute_padding`` (utility/functions.py:172-174,191-219) on top of the HIP model.
+Rates come from the in-kernel ``log2`` accumulators (a13), squared errors from ``vam_sqdiff_sum``.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def compute_padding(in_h: int, in_w: int, *, out_h=None, out_w=None, min_div=1):
+    """utility/functions.py:191-219: (left, right, top, bottom) pad and un-pad tuples to a multiple of min_div."""
+    if out_h is None:
+        out_h = (in_h + min_div - 1) // min_div * min_div
+    if out_w is None:
+        out_w = (in_w + min_div - 1) // min_div * min_div
+    if out_h % min_div != 0 or out_w % min_div != 0:
+        raise ValueError(f"Padded output height and width are not divisible by min_div={min_div}.")
+    left = (out_w - in_w) // 2
+    right = out_w - in_w - left
+    top = (out_h - in_h) // 2
+    bottom = out_h - in_h - top
+    return (left, right, top, bottom), (-left, -right, -top, -bottom)
+
+
+def pad_image(x: torch.Tensor, min_div: int = 64):
+    """test/utils.py:7-13: zero-pad to a multiple of 64 (6 stride-2 stages); returns (x_padded, unpad)."""
+    pad, unpad = compute_padding(x.size(2), x.size(3), min_div=min_div)
+    return torch.nn.functional.pad(x, pad, mode="constant", value=0), unpad
+
+
+def compute_psnr(a: torch.Tensor, b: torch.Tensor) -> float:
+    """utility/functions.py:172-174: -10 log10(mean((a-b)^2)) over the whole tensor pair."""
+    a, b = a.contiguous(), b.contiguous()
+    acc = torch.zeros(1, dtype=torch.float64, device=a.device)
+    ops.sqdiff_sum(a, b, acc)
+    return -10.0 * math.log10(acc.item() / a.numel())
+
+
+def estimated_bpp(out: dict, num_pixels: int) -> float:
+    """training/loss.py:217-228 (RateLoss): (sum log2 lik_y + sum log2 lik_z) / (-pixels)."""
+    return -out["log2_likelihood_sum"].sum().item() / num_pixels
+
+
+def _checkpoint_for(model, x, p):
+    """training/step.py:13-29 extract_quality_ref + ExtractChekpointRepr (REM models only)."""
+    levels = getattr(model, "check_levels", None)
+    if not levels or p <= levels[0]:
+        return None
+    q_ref = max(l for l in levels if l < p)
+    return model.ExtractChekpointRepr(x, quality=q_ref, rc=False)
+
+
+def test_epoch(batches: Iterable[torch.Tensor], model, pr_list: Sequence[float], rems: bool = False):
+    """training/step.py:206-243: likelihood-estimated (bpp, PSNR) averaged over the batches, per quality."""
+    bpp = [[] for _ in pr_list]
+    psnr = [[] for _ in pr_list]
+    with torch.no_grad():
+        for d in batches:
+            n_pix = d.shape[0] * d.shape[2] * d.shape[3]
+            for j, p in enumerate(pr_list):
+                ck = _checkpoint_for(model, d, p) if rems else None
+                out = model.forward_single_quality(d, quality=p, training=False, **({"checkpoint_ref": ck} if rems else {}))
+                bpp[j].append(estimated_bpp(out, n_pix))
+                psnr[j].append(compute_psnr(d, out["x_hat"]))
+    return [sum(v) / len(v) for v in bpp], [sum(v) / len(v) for v in psnr]
+
+
+def compress_with_ac(model, images: Iterable[torch.Tensor], pr_list: Sequence[float], rems: bool = False):
+    """training/step.py:259-358: real codec evaluation — compress + decompress every (unpadded) image at every
+    quality; bpp = 8 * bytes / pixels of the ORIGINAL image, PSNR on the cropped reconstruction.
+    Returns (bpp, psnr, enc_seconds, dec_seconds) lists per quality."""
+    nq = len(pr_list)
+    bpp, psnr, t_enc, t_dec = [[] for _ in range(nq)], [[] for _ in range(nq)], [[] for _ in range(nq)], [[] for _ in range(nq)]
+    with torch.no_grad():
+        for x in images:
+            xp, unpad = pad_image(x)
+            for j, p in enumerate(pr_list):
+                ck = _checkpoint_for(model, xp, p) if rems else None
+                t0 = time.perf_counter()
+                enc = model.compress(xp, quality=p, checkpoint_rep=ck)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dec = model.decompress(enc["strings"], enc["shape"], quality=p, checkpoint_rep=ck)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                x_hat = torch.nn.functional.pad(dec["x_hat"], unpad)
+                n_bytes = sum(len(s) for sl in enc["strings"][0] for s in sl) + sum(len(s) for s in enc["strings"][1])
+                bpp[j].append(8.0 * n_bytes / (x.shape[0] * x.shape[2] * x.shape[3]))
+                psnr[j].append(compute_psnr(x, x_hat))
+                t_enc[j].append(t1 - t0)
+                t_dec[j].append(t2 - t1)
+    avg = lambda rows: [sum(v) / len(v) for v in rows]
+    return avg(bpp), avg(psnr), avg(t_enc), avg(t_dec)

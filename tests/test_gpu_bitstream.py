@@ -118,3 +118,23 @@ def test_progressive_container_layers(codec):
             # evaluated through differently shaped launches, hence the 1e-5)
             assert (dk["y_prog"] - fw["y_hat"]).abs().max().item() <= 1e-4
             assert (dk["x_hat"].clamp(0, 1) - fw["x_hat"]).abs().max().item() <= 1e-5
+
+
+def test_eval_drivers(codec):
+    """test_epoch / compress_with_ac counterparts (reference training/step.py:206-358) incl. padding of a
+    non-multiple-of-64 image and PSNR via vam_sqdiff_sum."""
+    from vampic import evaluate as EV
+    import vampic_oracle as O
+    net = codec
+    x = synth.synth_image(1, 64, 128, seed=10)[:, :, :50, :100].contiguous().cuda()      # 50 x 100 image
+    (pad, unpad) = EV.compute_padding(50, 100, min_div=64)
+    assert pad == (14, 14, 7, 7) and unpad == (-14, -14, -7, -7)
+    bpp, psnr, te, td = EV.compress_with_ac(net, [x], [0, 2.5])
+    assert len(bpp) == 2 and bpp[1] > bpp[0] > 0 and all(p > 0 for p in psnr)
+    xp, _ = EV.pad_image(x)
+    e_bpp, e_psnr = EV.test_epoch([xp], net, [0, 2.5])
+    with torch.no_grad():
+        out = net.forward_single_quality(xp, 2.5)
+    assert abs(e_psnr[1] - O.psnr(xp.cpu(), out["x_hat"].cpu())) < 1e-4
+    assert abs(e_bpp[1] - O.bpp({k: v.cpu() for k, v in out["likelihoods"].items()}, 64 * 128)) < 1e-6 * e_bpp[1]
+    print("real codec: bpp", bpp, "psnr", psnr, "enc s", te, "dec s", td)
