@@ -19,7 +19,7 @@ ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQR
 # enum vam_conv_flags
 CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW = 1, 2, 4
 # enum vam_pack_mode
-PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN = range(4)
+PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD = range(5)
 # enum vam_family
 FAM_CONV, FAM_ATTN, FAM_MASK, FAM_TAIL, FAM_MISC = range(5)
 FAMILY_NAMES = ("conv_igemm", "win_attn", "variance_mask", "gauss_tail", "misc")
@@ -80,6 +80,12 @@ _SIGNATURES = {
     "vam_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vam_sqdiff_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
+    "vam_eb_forward_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),
+    "vam_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vam_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "vam_leaky_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    "vam_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    "vam_gauss_train": (C.c_int, [C.c_void_p, C.c_int] * 10 + [C.c_long, C.c_int, C.c_void_p]),
     "vam_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_rans_encode": (C.c_long, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "vam_rans_decode": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

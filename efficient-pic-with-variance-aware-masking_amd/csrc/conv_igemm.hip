@@ -457,6 +457,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
       int cq = n / 4;
       int ph = nn / cq, c = nn - ph * cq;
       v = src[(((size_t)(c * 4 + ph) * cin + cc) * kh + ty) * kw + tx];
+    } else if (mode == VAM_PACK_CONV_DGRAD) {
+      // data gradient of a stride-1 conv = correlation of dY with the taps flipped and the channel roles
+      // swapped: here `cin` = forward Cout (channels of dY), `n` = forward Cin; src is the forward OIHW tensor
+      v = src[(((size_t)cc * n + nn) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
     } else if (mode == VAM_PACK_GDN) {
       float g = src[(size_t)nn * cin + cc];
       const float bound = 3.814697265625e-06f;       // 2^-18 = sqrt(0 + 2^-36)
@@ -551,7 +555,7 @@ size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
 int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int kh, int kw, int cin, int n,
                           void* stream) {
   VAM_REQUIRE(src && dst && kh > 0 && kw > 0 && cin > 0 && n > 0, "vam_pack_conv_weights: bad arguments");
-  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_GDN, "vam_pack_conv_weights: bad mode %d", mode);
+  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_CONV_DGRAD, "vam_pack_conv_weights: bad mode %d", mode);
   if (mode == VAM_PACK_PS2) VAM_REQUIRE(n % 4 == 0, "PS2 pack needs N %% 4 == 0");
   if (mode == VAM_PACK_DECONV5S2 && phase < 0) VAM_REQUIRE(n % 4 == 0 && kh == 3 && kw == 3, "merged deconv pack needs 3x3, N=4*Cout");
   if (mode == VAM_PACK_DECONV5S2 && phase >= 0)

@@ -221,7 +221,8 @@ __device__ __forceinline__ float eb_logits(const float* sp /*61 preprocessed flo
 
 __global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ params, int C,
                                   float* __restrict__ zhat, int ld_zhat, float* __restrict__ lik, int ld_lik,
-                                  int32_t* __restrict__ sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix) {
+                                  int32_t* __restrict__ sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
+                                  const float* __restrict__ noise, int ld_noise) {
   // one thread per channel (blockDim.x >= C), pixels strided over blockIdx / y
   extern __shared__ float sh[];  // C * 62 floats of preprocessed params
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -262,8 +263,10 @@ __global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const f
     const float qz = rintf(v - med);
     float o = qz + med;                           // quantize "dequantize" with medians
     if (sym) sym[p * ld_sym + c] = (int)qz;       // quantize "symbols" (entropy_models.py:151-153)
-    float lower = eb_logits(sp, o - 0.5f);
-    float upper = eb_logits(sp, o + 0.5f);
+    // training: the likelihood is evaluated at z + U(-.5,.5) (quantize "noise", entropy_models.py:132-138,471-473)
+    const float at = noise ? v + noise[p * ld_noise + c] : o;
+    float lower = eb_logits(sp, at - 0.5f);
+    float upper = eb_logits(sp, at + 0.5f);
     float sum = lower + upper;
     float sign = sum > 0.f ? -1.f : (sum < 0.f ? 1.f : 0.f);   // -sign(lower+upper)
     float su = 1.0f / (1.0f + expf(-(sign * upper)));
@@ -382,6 +385,14 @@ int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int l
 
 int vam_eb_forward(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat, float* lik,
                    int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix, void* stream) {
+  return vam_eb_forward_noise(z, ld_z, params, C, zhat, ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix,
+                              nullptr, 0, stream);
+}
+
+int vam_eb_forward_noise(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat, float* lik,
+                         int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
+                         const float* noise, int ld_noise, void* stream) {
+  VAM_REQUIRE(!noise || ld_noise >= C, "vam_eb_forward_noise: noise stride");
   VAM_REQUIRE(z && params && C > 0 && C <= 1024 && n_pix > 0, "vam_eb_forward: bad arguments");
   VAM_REQUIRE(!log2sum || pix_per_item > 0, "vam_eb_forward: pix_per_item");
   int block = (C + 63) / 64 * 64;
@@ -390,7 +401,7 @@ int vam_eb_forward(const float* z, int ld_z, const float* params, int C, float* 
   unsigned grid = (unsigned)(n_pix < 1024 ? n_pix : 1024);
   ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
   hipLaunchKernelGGL(eb_forward_kernel, dim3(grid), dim3(block), smem, (hipStream_t)stream, z, ld_z, params, C, zhat,
-                     ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix);
+                     ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix, noise, ld_noise);
   return check_launch("eb_forward_kernel");
 }
 

@@ -370,6 +370,158 @@ def lower_rem_blocks(plan: Plan, mods: Sequence[Ly.LatentRateReduction], y_cks: 
     plan.conv(probs)
 
 
+# =============================================================================
+# REM fine-tune: taped forward + backward lowering            (train.py:223-226, training/step.py:56-95)
+# =============================================================================
+class TrainPacks:
+    """Persistent packed weights of the TRAINED convolutions (forward form and data-gradient form), refreshed
+    in place at the head of every step: the optimiser changes the parameters between steps while the plan's
+    pre-marshalled launches keep their pointers."""
+
+    def __init__(self, convs: Sequence[Ly.Conv2d], need_dgrad: Sequence[Ly.Conv2d]):
+        self.convs = list(convs)
+        self.f = {id(c): ops.pack_conv(c.weight, c.bias, 1) for c in self.convs}
+        self.d = {id(c): ops.pack_conv_dgrad(c.weight) for c in need_dgrad}
+        self._dg = list(need_dgrad)
+
+    def fwd(self, c) -> ops.Packed:
+        return self.f[id(c)]
+
+    def dgrad(self, c) -> ops.Packed:
+        return self.d[id(c)]
+
+    def record_refresh(self, plan: Plan):
+        def refresh():
+            for c in self.convs:
+                ops.repack_conv(c.weight, c.bias, self.f[id(c)])
+            for c in self._dg:
+                ops.repack_conv(c.weight, None, self.d[id(c)], dgrad=True)
+        plan.call(refresh, f"repack {len(self.convs)}+{len(self._dg)} trained convs")
+
+
+def rem_trained_convs(mods: Sequence[Ly.LatentRateReduction]):
+    """(all convs, convs whose data gradient is needed) of K REM blocks.  The first ResidualBlock of each of the
+    three input branches feeds from frozen tensors, so its conv1 / skip need no data gradient."""
+    allc, dg = [], []
+    for m in mods:
+        for name in ("enc_base_rep", "enc_progressive_entropy_params", "enc_base_entropy_params", "enc"):
+            for d, rb in enumerate(getattr(m, name)):
+                cs = [rb.conv1, rb.conv2] + ([rb.skip] if rb.skip is not None else [])
+                allc += cs
+                dg.append(rb.conv2)
+                if name == "enc" or d > 0:
+                    dg += [rb.conv1] + ([rb.skip] if rb.skip is not None else [])
+    return allc, dg
+
+
+def _rb_forward_taped(plan: Plan, blocks, ins, packs: TrainPacks):
+    """ResidualBlock forward keeping what the backward needs: h1a = LeakyReLU(conv1 x), o2 = LeakyReLU(conv2 h1a)
+    (the sign of a LeakyReLU's output is the sign of its input), out = o2 + skip(x)."""
+    h = [plan.buf(i[0].B, i[0].H, i[0].W, b.conv1.out_channels) for b, i in zip(blocks, ins)]
+    probs = [ops.conv_problem(packs.fwd(b.conv1), i, o, L.ACT_LEAKY) for b, i, o in zip(blocks, ins, h)]
+    idn = []
+    for b, i in zip(blocks, ins):
+        if b.skip is not None:
+            sv = plan.buf(i[0].B, i[0].H, i[0].W, b.skip.out_channels)
+            probs.append(ops.conv_problem(packs.fwd(b.skip), i, sv))
+            idn.append(sv)
+        else:
+            assert len(i) == 1
+            idn.append(i[0])
+    plan.conv(probs)
+    o2 = [plan.buf(v.B, v.H, v.W, b.conv2.out_channels) for b, v in zip(blocks, h)]
+    plan.conv([ops.conv_problem(packs.fwd(b.conv2), [hv], o, L.ACT_LEAKY) for b, hv, o in zip(blocks, h, o2)])
+    outs = [plan.buf(v.B, v.H, v.W, v.C) for v in o2]
+    for a, b_, o in zip(o2, idn, outs):
+        plan.call(lambda a=a, b_=b_, o=o: ops.add(b_, a, o), "rb residual add")     # same order as post + act(.)
+    recs = [dict(block=b, x=list(i), h1a=hv, o2=o) for b, i, hv, o in zip(blocks, ins, h, o2)]
+    return outs, recs
+
+
+def lower_rem_blocks_train(plan: Plan, mods, y_cks, ep_bases, ep_progs, atts, outs, packs: TrainPacks) -> dict:
+    """Forward of K REM blocks (same arithmetic as :func:`lower_rem_blocks`) recording a tape."""
+    K = len(mods)
+    m0 = mods[0]
+    assert all(m.mu_std for m in mods)
+    names = ["enc_base_rep", "enc_progressive_entropy_params", "enc_base_entropy_params"]
+    cur = [[y] for y in y_cks] + [list(e) for e in ep_progs] + [list(e) for e in ep_bases]
+    tape = {"branch": [], "enc": [], "K": K}
+    for d in range(len(m0.enc_base_rep)):
+        blocks = [getattr(m, n)[d] for n in names for m in mods]
+        r, recs = _rb_forward_taped(plan, blocks, cur, packs)
+        tape["branch"].append(recs)
+        cur = [[v] for v in r]
+    t = [[cur[k][0], cur[2 * K + k][0], cur[K + k][0]] for k in range(K)]       # latent, base, prog (rem.py:137)
+    for d in range(len(m0.enc)):
+        r, recs = _rb_forward_taped(plan, [m.enc[d] for m in mods], t, packs)
+        tape["enc"].append(recs)
+        t = [[v] for v in r]
+    N = m0.dim_block
+    pk = _identity_pack(N, t[0][0].buf.device)
+    probs = []
+    for k in range(K):
+        ret = t[k][0]
+        for half, (idv, o) in enumerate(zip(ep_progs[k], outs[k])):
+            probs.append(ops.conv_problem(pk, [ret.window(half * N, N)], o, L.ACT_NONE, mul=atts[k], post=idv))
+    plan.conv(probs)
+    return tape
+
+
+def _rb_backward(plan: Plan, recs, d_outs, need_dx: bool, packs: TrainPacks, grads: Dict[int, torch.Tensor]):
+    """Backward of K ResidualBlocks in lockstep.  ``grads[id(param)]`` are the gradient buffers (parameter
+    layout).  Returns dL/dx per block (one View over the concatenated input channels) or None."""
+    g = lambda p: grads[id(p)]
+    dh2 = [plan.buf(r["o2"].B, r["o2"].H, r["o2"].W, r["o2"].C) for r in recs]
+    for r, do, t in zip(recs, d_outs, dh2):
+        plan.call(lambda r=r, do=do, t=t: ops.leaky_bwd(r["o2"], do, t), "leaky bwd")
+        b = r["block"]
+        plan.call(lambda r=r, t=t, b=b: ops.conv_wgrad([r["h1a"]], t, g(b.conv2.weight), g(b.conv2.bias)), "wgrad conv2")
+    dh1a = [plan.buf(r["h1a"].B, r["h1a"].H, r["h1a"].W, r["h1a"].C) for r in recs]
+    plan.conv([ops.conv_problem(packs.dgrad(r["block"].conv2), [t], o) for r, t, o in zip(recs, dh2, dh1a)])
+    dh1 = [plan.buf(v.B, v.H, v.W, v.C) for v in dh1a]
+    for r, a, t, do in zip(recs, dh1a, dh1, d_outs):
+        b = r["block"]
+        plan.call(lambda r=r, a=a, t=t: ops.leaky_bwd(r["h1a"], a, t), "leaky bwd")
+        plan.call(lambda r=r, t=t, b=b: ops.conv_wgrad(r["x"], t, g(b.conv1.weight), g(b.conv1.bias)), "wgrad conv1")
+        if b.skip is not None:
+            plan.call(lambda r=r, do=do, b=b: ops.conv_wgrad(r["x"], do, g(b.skip.weight), g(b.skip.bias)), "wgrad skip")
+    if not need_dx:
+        return None
+    cin = [sum(v.C for v in r["x"]) for r in recs]
+    dx = [plan.buf(r["o2"].B, r["o2"].H, r["o2"].W, c) for r, c in zip(recs, cin)]
+    via = []
+    sk = [(r, do) for r, do in zip(recs, d_outs) if r["block"].skip is not None]
+    if sk:
+        tmp = {id(r): plan.buf(r["o2"].B, r["o2"].H, r["o2"].W, c) for (r, _), c in zip(sk, [sum(v.C for v in r["x"]) for r, _ in sk])}
+        plan.conv([ops.conv_problem(packs.dgrad(r["block"].skip), [do], tmp[id(r)]) for r, do in sk])
+    for r, do in zip(recs, d_outs):
+        via.append(tmp[id(r)] if r["block"].skip is not None else do)
+    plan.conv([ops.conv_problem(packs.dgrad(r["block"].conv1), [t], o, post=p_)
+               for r, t, o, p_ in zip(recs, dh1, dx, via)])
+    return dx
+
+
+def lower_rem_backward(plan: Plan, tape: dict, mods, d_mu: Sequence[View], d_sigma: Sequence[View], atts: Sequence[View],
+                       packs: TrainPacks, grads: Dict[int, torch.Tensor]):
+    """dL/d(REM parameters) from dL/d(mu', sigma') of K slices: res = identity + ret * att  (rem.py:139-141),
+    so d ret = d res * att; nothing upstream of the REM inputs is trainable (train.py:223-226)."""
+    K = tape["K"]
+    N = mods[0].dim_block
+    d_ret = [plan.buf(d_mu[k].B, d_mu[k].H, d_mu[k].W, 2 * N) for k in range(K)]
+    for k in range(K):
+        plan.call(lambda k=k: ops.mul(d_mu[k], atts[k], d_ret[k].window(0, N)), "d ret (mu half)")
+        plan.call(lambda k=k: ops.mul(d_sigma[k], atts[k], d_ret[k].window(N, N)), "d ret (sigma half)")
+    d = d_ret
+    for recs in reversed(tape["enc"]):
+        d = _rb_backward(plan, recs, d, True, packs, grads)
+    # d[k]: gradient of cat(f_latent, f_base, f_prog); branch order in the tape: latent x K, prog x K, base x K
+    d_branch = [d[k].window(0, N) for k in range(K)] + [d[k].window(2 * N, N) for k in range(K)] + \
+               [d[k].window(N, N) for k in range(K)]
+    depth = len(tape["branch"])
+    for i, recs in enumerate(reversed(tape["branch"])):
+        d_branch = _rb_backward(plan, recs, d_branch, i < depth - 1, packs, grads)
+
+
 _ONE_BY_ONE: Dict[tuple, ops.Packed] = {}
 
 

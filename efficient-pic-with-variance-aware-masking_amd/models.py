@@ -196,6 +196,19 @@ class VarianceMaskingPIC(CompressionModel):
         self._dec_plans.clear()
         return super()._apply(fn, *a, **k)
 
+    def __deepcopy__(self, memo):
+        """Plans hold device pointers, HIP graphs and streams of THIS instance: a copy starts without them."""
+        import copy
+        held = self._plans, self._dec_plans
+        self._plans, self._dec_plans = {}, {}
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            new.__dict__ = copy.deepcopy(self.__dict__, memo)
+        finally:
+            self._plans, self._dec_plans = held
+        return new
+
     def define_quality(self, quality):
         if quality is None:
             return self.quality_list
@@ -235,14 +248,17 @@ class VarianceMaskingPIC(CompressionModel):
                                       "(dual encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable, "
                                       "dim_chunk 32, division [d, 2d], 5 support slices)")
 
-    def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False) -> "_FsqPlan":
+    def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False,
+              train: bool = False) -> "_FsqPlan":
         B, C_, H, W = x.shape
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
-        key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ())
+        key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ())
         p = self._plans.get(key)
+        if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
+            p = None                # the REM was fine-tuned since this plan packed its weights
         if p is None:
-            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols)
+            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train)
             self._plans[key] = p
         return p
 
@@ -305,6 +321,8 @@ class VarianceMaskingPIC(CompressionModel):
         y_strings: List[List[bytes]] = []
         if real_compress:
             from . import bitstream as bs
+            if plan.idx is None:
+                raise ValueError("empty scale table: call model.update() before compress()")
             tg, te = bs.Tables.of(self.gaussian_conditional), bs.Tables.of(self.entropy_bottleneck)
             sym = plan.sym.buf.cpu().numpy()           # [B,h,w,C_lat] int32 (synchronises)
             idx = plan.idx.buf.cpu().numpy()
@@ -342,8 +360,11 @@ class VarianceMaskingPIC(CompressionModel):
         rem_idx = None if base_only else self._rem_choice(quality, checkpoint_rep)
         key = (B, hz, wz, base_only, rem_idx, str(dev))
         dp = self._dec_plans.get(key)
+        if dp is not None and rem_idx is not None and dp.rem_sig != _version_sig(self.post_latent[rem_idx]):
+            dp = None               # REM fine-tuned since the plan packed its weights
         if dp is None:
             dp = _DecPlan(self, B, hz, wz, base_only, rem_idx, dev)
+            dp.rem_sig = _version_sig(self.post_latent[rem_idx]) if rem_idx is not None else None
             self._dec_plans[key] = dp
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
         return {"x_hat": dp.decode(strings, pr, checkpoint_rep if rem_idx is not None else None)}
@@ -418,14 +439,16 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         return 2
 
     def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, checkpoint_ref=None,
-                               clone=True):
+                               clone=True, noise=None):
         return self.forward(x=x, quality=quality, mask_pol=mask_pol, training=training, checkpoint_ref=checkpoint_ref,
-                            clone=clone)
+                            clone=clone, noise=noise)
 
-    def forward(self, x, mask_pol="point-based-std", quality=0, training=True, checkpoint_ref=None, clone=True):
-        """models/rem_pic.py:229-422 (eval)."""
+    def forward(self, x, mask_pol="point-based-std", quality=0, training=True, checkpoint_ref=None, clone=True,
+                noise=None):
+        """models/rem_pic.py:229-422.  ``training=True`` is the REM fine-tune forward (BASELINE configs[4]):
+        additive-noise likelihoods, autograd-connected to the ``post_latent`` parameters only."""
         if training:
-            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+            return self._forward_train(x, mask_pol, quality, checkpoint_ref, noise)
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
             raise NotImplementedError()
@@ -438,6 +461,32 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
         plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
         return plan.execute(x, pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, clone)
+
+    def _forward_train(self, x, mask_pol, quality, checkpoint_ref, noise):
+        """Training-mode forward (rem_pic.py:229-422 with training=True; training/step.py:62-76).  Everything
+        outside ``post_latent`` must be frozen (``freeze_all(); unfreeze_rems()``): those transforms have no
+        backward kernels in this build, and silently dropping their gradients would be wrong."""
+        rem_ids = {id(p) for p in self.post_latent.parameters()}
+        loose = [n for n, p in self.named_parameters() if p.requires_grad and id(p) not in rem_ids]
+        if loose:
+            raise NotImplementedError("training-mode forward is built for --training_type rems only (call freeze_all(); "
+                                      f"unfreeze_rems()); trainable non-REM parameters: {loose[:3]}...")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        L.require_gpu()
+        self._check_config()
+        if not self.mu_std:
+            raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
+        if checkpoint_ref is not None:
+            checkpoint_ref = checkpoint_ref.detach()
+        rem_idx = self._rem_choice(quality, checkpoint_ref) if quality != 0 else None
+        pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
+        plan = self._plan(x.detach(), base_only=(quality == 0), rem_idx=rem_idx, train=True)
+        out = plan.execute(x.detach(), pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, True, noise=noise)
+        if rem_idx is not None and torch.is_grad_enabled() and any(p.requires_grad for p in plan.rem_params):
+            out["likelihoods"]["y"] = _RemTrainFn.apply(plan, out["likelihoods"]["y"], self.use_graph, *plan.rem_params)
+        return out
 
     def apply_latent_enhancement(self, current_index, quality, quality_bar, y_b_hat, mu_scale_base, mu_scale_enh,
                                  mu, scale, training=False, mask_pol="point-based-std", attention_mask=None):
@@ -473,13 +522,34 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
 
 
 # ----------------------------------------------------------------------------- the fused plan
+def _version_sig(mod: nn.Module):
+    return tuple(p._version for p in mod.parameters())
+
+
+class _RemTrainFn(torch.autograd.Function):
+    """likelihoods["y"] of the training-mode REM forward as a differentiable function of the REM parameters
+    (the only trainable ones under ``--training_type rems``, train.py:223-226)."""
+
+    @staticmethod
+    def forward(ctx, plan, lik_y, use_graph, *params):
+        ctx.plan, ctx.use_graph = plan, use_graph
+        return lik_y.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.plan.backward(g, ctx.use_graph)
+        return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
 class _FsqPlan:
     """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
 
-    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False):
+    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False, train=False):
         self.m, self.B, self.H, self.W = m, B, H, W
         self.base_only, self.rem_idx = base_only, rem_idx
         self.symbols = symbols
+        self.train = train          # additive-noise likelihoods (+ taped REM and a backward plan when rem_idx is set)
+        self.bwd = None
         self.pr = 0.0
         self.graphs: Dict[float, ops.Graph] = {}
         self.stream = None
@@ -509,7 +579,10 @@ class _FsqPlan:
         self.z_lik = plan.buf(B, h // 4, w // 4, m.N)
         self.z_sym = ops.new_iview(B, h // 4, w // 4, m.N, device) if symbols else None
         plan.keep.append(self.z_sym)
-        plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z, sym=self.z_sym))
+        self.noise_z = plan.buf(B, h // 4, w // 4, m.N) if train else None
+        self.noise_y = plan.buf(B, h, w, d if base_only else 2 * d) if train else None
+        plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z, sym=self.z_sym,
+                                         noise=self.noise_z))
         nh = 1 if base_only else 2
         means_h = plan.buf(B, h, w, nh * d)
         scales_h = plan.buf(B, h, w, nh * d)
@@ -526,11 +599,10 @@ class _FsqPlan:
         self.lik = plan.buf(B, h, w, d if base_only else 2 * d)
         # entropy-coder inputs (compress only): quantised symbols and scale-table indexes
         self.sym = ops.new_iview(B, h, w, d if base_only else 2 * d, device) if symbols else None
-        self.idx = ops.new_iview(B, h, w, d if base_only else 2 * d, device) if symbols else None
-        plan.keep += [self.sym, self.idx]
         table = m.gaussian_conditional.scale_table
-        if symbols and table.numel() == 0:
-            raise ValueError("empty scale table: call model.update() before compress()")
+        indexes = symbols and table.numel() > 0        # without update() only real_compress=False is possible
+        self.idx = ops.new_iview(B, h, w, d if base_only else 2 * d, device) if indexes else None
+        plan.keep += [self.sym, self.idx]
         sl = lambda v, i, n=1: v.window(i * C, n * C)
         mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
 
@@ -543,7 +615,10 @@ class _FsqPlan:
             plan.call(lambda: ops.gauss_tail(sl(y, i0, n), sl(self.mu_b, i0, n), sl(self.std_b, i0, n),
                                              yhat=sl(yq, i0, n), lik=sl(self.lik, i0, n), log2sum=ls_y,
                                              sym=sl(self.sym, i0, n) if symbols else None))
-            if symbols:                                                               # pic.py:737
+            if train:        # quantize "noise": likelihood at y + U(-.5,.5) - mu (entropy_models.py:132-138,643-651)
+                plan.call(lambda: ops.gauss_train(sl(y, i0, n), sl(self.mu_b, i0, n), sl(self.std_b, i0, n),
+                                                  sl(self.noise_y, i0, n), lik=sl(self.lik, i0, n)))
+            if indexes:                                                               # pic.py:737
                 plan.call(lambda: ops.build_indexes(sl(self.std_b, i0, n), table, out=sl(self.idx, i0, n)))
             E.lower_stacks(plan, [m.lrp_transforms[i] for i in idx], [[mh0] + sup + [sl(yq, i)] for i in idx],
                            [sl(yb, i) for i in idx],
@@ -595,11 +670,20 @@ class _FsqPlan:
             att = plan.buf(B, h, w, d)
             plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
             mu_f, std_f = plan.buf(B, h, w, d), plan.buf(B, h, w, d)
-            E.lower_rem_blocks(plan, [m.post_latent[rem_idx][j] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
-                               [[sl(self.mu_b, j), sl(self.std_b, j)] for j in range(ns)],
-                               [[sl(self.mu_p, j), sl(self.std_p, j)] for j in range(ns)],
-                               [sl(att, j) for j in range(ns)],
-                               [[sl(mu_f, j), sl(std_f, j)] for j in range(ns)])
+            mods = [m.post_latent[rem_idx][j] for j in range(ns)]
+            rem_io = ([sl(self.ck, j) for j in range(ns)],
+                      [[sl(self.mu_b, j), sl(self.std_b, j)] for j in range(ns)],
+                      [[sl(self.mu_p, j), sl(self.std_p, j)] for j in range(ns)],
+                      [sl(att, j) for j in range(ns)],
+                      [[sl(mu_f, j), sl(std_f, j)] for j in range(ns)])
+            if train:
+                self.rem_params = [p for mod in mods for p in mod.parameters()]
+                self.packs = E.TrainPacks(*E.rem_trained_convs(mods))
+                self.packs.record_refresh(plan)
+                tape = E.lower_rem_blocks_train(plan, mods, *rem_io, self.packs)
+            else:
+                self.rem_sig = _version_sig(m.post_latent[rem_idx])
+                E.lower_rem_blocks(plan, mods, *rem_io)
         self.mu_f, self.std_f = mu_f, std_f
         self.mask = plan.buf(B, h, w, d)
         self.thr = torch.empty((B * ns,), **f32)
@@ -609,7 +693,26 @@ class _FsqPlan:
         plan.call(lambda: ops.gauss_tail(y.window(d, d), mu_f, std_f, y2=y.window(0, d), mask=self.mask, yhat=rq,
                                          lik=self.lik.window(d, d), log2sum=ls_y,
                                          sym=self.sym.window(d, d) if symbols else None))           # pic.py:625-629
-        if symbols:                                                                   # pic.py:813
+        if train:
+            yr, y0, nz = y.window(d, d), y.window(0, d), self.noise_y.window(d, d)
+            plan.call(lambda: ops.gauss_train(yr, mu_f, std_f, nz, y2=y0, mask=self.mask, lik=self.lik.window(d, d)))
+            if rem_idx is not None:
+                # ---- backward plan: dL/dlik (progressive half) -> (dmu', dsigma') -> REM parameters
+                bw = self.bwd = E.Plan(device)
+                self.glik = bw.buf(B, h, w, d)
+                dmu, dsg = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                flat = torch.zeros(sum(p.numel() for p in self.rem_params), **f32)
+                self.gflat, self.gviews, off = flat, [], 0
+                for p in self.rem_params:
+                    self.gviews.append(flat[off:off + p.numel()].view(p.shape))
+                    off += p.numel()
+                grads = {id(p): g for p, g in zip(self.rem_params, self.gviews)}
+                bw.keep += [flat, self.gviews]
+                bw.call(lambda: ops.gauss_train(yr, mu_f, std_f, nz, y2=y0, mask=self.mask, grad_lik=self.glik,
+                                                dmu=dmu, dsigma=dsg), "likelihood backward")
+                E.lower_rem_backward(bw, tape, mods, [sl(dmu, j) for j in range(ns)], [sl(dsg, j) for j in range(ns)],
+                                     rem_io[3], self.packs, grads)
+        if indexes:                                                                   # pic.py:813
             plan.call(lambda: ops.build_indexes(std_f, table, mask=self.mask, out=self.idx.window(d, d)))
         yp = self.y_prog = plan.buf(B, h, w, d)
         E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
@@ -618,16 +721,57 @@ class _FsqPlan:
         E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
 
     # -------------------------------------------------------------------------------------------
-    def execute(self, x, pr, checkpoint_ref, use_graph, clone):
+    def set_noise(self, noise=None):
+        """Training: U(-.5,.5) for the likelihood proxies; ``noise`` = {"y": NCHW, "z": NCHW} injects fixed draws
+        (parity tests), otherwise torch's generator fills the buffers like the reference's ``uniform_``."""
+        for key, v in (("y", self.noise_y), ("z", self.noise_z)):
+            if noise is not None and key in noise:
+                v.buf.copy_(noise[key].to(v.buf.device).permute(0, 2, 3, 1))
+            else:
+                v.buf.uniform_(-0.5, 0.5)
+
+    def backward(self, grad_lik_y: torch.Tensor, use_graph: bool):
+        """dL/d(REM parameters) for dL/dlikelihoods["y"] (NCHW); returns fresh tensors in ``rem_params`` order."""
+        d = self.m.division_dimension[0]
+        cur = torch.cuda.current_stream(self.x_in.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.glik.buf.copy_(grad_lik_y[:, d:].permute(0, 2, 3, 1))
+            if use_graph:
+                if getattr(self, "_bwd_graph", None) is None:
+                    self.bwd.run()
+                    self.stream.synchronize()
+                    self._bwd_graph = ops.Graph()
+                    self._bwd_graph.capture(self.bwd.run)
+                self._bwd_graph.launch()
+            else:
+                self.bwd.run()
+            flat = self.gflat.clone()
+        cur.wait_stream(self.stream)
+        out, off = [], 0
+        for p in self.rem_params:
+            out.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return out
+
+    def execute(self, x, pr, checkpoint_ref, use_graph, clone, noise=None):
         """Run the plan on the model's own HIP stream (hipGraph capture is not allowed on the
         legacy default stream), ordered after / before the caller's current stream."""
         self.pr = float(pr)
+        if self.train and self.rem_idx is not None:
+            sig = tuple(p.data_ptr() for p in self.rem_params)
+            if getattr(self, "_ptr_sig", sig) != sig:          # parameter storage replaced: captured pointers are stale
+                self.graphs.clear()
+                self._bwd_graph = None
+            self._ptr_sig = sig
         cur = torch.cuda.current_stream(self.x_in.device)
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.x_in.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self.x_in.copy_(x)
+            if self.train:
+                self.set_noise(noise)
             if checkpoint_ref is not None:
                 ck = ops.from_nchw(checkpoint_ref.to(self.x_in.device))
                 self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])

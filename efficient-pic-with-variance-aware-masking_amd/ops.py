@@ -102,6 +102,18 @@ def pack_weights(src: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin
     return dst
 
 
+def repack_conv(conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], pk: "Packed", dgrad: bool = False):
+    """Refresh ``pk`` IN PLACE from the (trained) parameters: plans keep pointing at the same packed buffers
+    while the optimiser updates the weights between steps."""
+    lib = L.load()
+    assert conv_weight.is_cuda and conv_weight.is_contiguous() and conv_weight.dtype == torch.float32
+    mode = L.PACK_CONV_DGRAD if dgrad else L.PACK_CONV
+    L.check(lib.vam_pack_conv_weights(conv_weight.data_ptr(), pk.w.data_ptr(), mode, 0, pk.kh, pk.kw, pk.cin, pk.n,
+                                      stream_ptr()), "vam_pack_conv_weights")
+    if not dgrad and conv_bias is not None:
+        L.check(lib.vam_pack_bias(conv_bias.data_ptr(), pk.b.data_ptr(), L.PACK_CONV, pk.n, stream_ptr()), "vam_pack_bias")
+
+
 def pack_bias(src: torch.Tensor, mode: int, n: int) -> torch.Tensor:
     lib = L.load()
     src = src.detach().to(dtype=torch.float32).contiguous()
@@ -320,15 +332,54 @@ def dequantize(sym: IView, mu: Optional[View], out: View):
 
 
 def eb_forward(z: View, params: torch.Tensor, zhat: Optional[View], lik: Optional[View],
-               log2sum: Optional[torch.Tensor] = None, sym: Optional[IView] = None):
+               log2sum: Optional[torch.Tensor] = None, sym: Optional[IView] = None, noise: Optional[View] = None):
     def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
-    L.check(L.load().vam_eb_forward(z.ptr, z.ld, params.data_ptr(), z.C, *p(zhat), *p(lik), *p(sym),
-                                    log2sum.data_ptr() if log2sum is not None else None, z.H * z.W, z.n_pix,
-                                    stream_ptr()), "vam_eb_forward")
+    L.check(L.load().vam_eb_forward_noise(z.ptr, z.ld, params.data_ptr(), z.C, *p(zhat), *p(lik), *p(sym),
+                                          log2sum.data_ptr() if log2sum is not None else None, z.H * z.W, z.n_pix,
+                                          *p(noise), stream_ptr()), "vam_eb_forward")
 
 
 def add(a: View, b: View, out: View):
     L.check(L.load().vam_add(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.n_pix, a.C, stream_ptr()), "vam_add")
+
+
+# ---- REM fine-tune backward pieces (csrc/train.hip)
+def pack_conv_dgrad(weight: torch.Tensor) -> Packed:
+    """Weights of the data-gradient conv of a stride-1 ``nn.Conv2d`` (taps flipped, channel roles swapped)."""
+    n_out, c_in, kh, kw = weight.shape
+    w = pack_weights(weight, L.PACK_CONV_DGRAD, 0, kh, kw, n_out, c_in)
+    return Packed(w, None, kh, kw, n_out, c_in, 1, kh // 2, kw // 2)
+
+
+def conv_wgrad(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]):
+    """dw (OIHW) / db of a stride-1 conv whose input was the channel concat of ``x_segs``."""
+    lib = L.load()
+    n, cin_total, kh, kw = dw.shape
+    assert dy.C == n and sum(v.C for v in x_segs) == cin_total and dw.is_contiguous()
+    off = 0
+    for v in x_segs:
+        L.check(lib.vam_conv_wgrad(v.ptr, v.ld, dy.ptr, dy.ld, v.B, v.H, v.W, kh, kw, v.C, n, dw.data_ptr(), cin_total, off,
+                                   stream_ptr()), "vam_conv_wgrad")
+        off += v.C
+    if db is not None:
+        L.check(lib.vam_colsum(dy.ptr, dy.ld, dy.n_pix, n, db.data_ptr(), stream_ptr()), "vam_colsum")
+
+
+def leaky_bwd(act: View, dy: View, dx: View):
+    L.check(L.load().vam_leaky_bwd(act.ptr, act.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, dx.n_pix, dx.C, stream_ptr()), "vam_leaky_bwd")
+
+
+def mul(a: View, b: View, out: View):
+    L.check(L.load().vam_mul(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, out.n_pix, out.C, stream_ptr()), "vam_mul")
+
+
+def gauss_train(y: View, mu: View, sigma: View, noise: View, *, y2: Optional[View] = None, mask: Optional[View] = None,
+                lik: Optional[View] = None, grad_lik: Optional[View] = None, dmu: Optional[View] = None,
+                dsigma: Optional[View] = None):
+    """Noisy-likelihood forward (``lik``) or backward (``grad_lik`` -> ``dmu``, ``dsigma``)."""
+    def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
+    L.check(L.load().vam_gauss_train(*p(y), *p(y2), *p(mu), *p(sigma), *p(mask), *p(noise), *p(grad_lik), *p(lik),
+                                     *p(dmu), *p(dsigma), y.n_pix, y.C, stream_ptr()), "vam_gauss_train")
 
 
 def memset_zero(t: torch.Tensor):

@@ -114,8 +114,11 @@ enum vam_pack_mode {
                             3x3 / N = 4*Cout phase-major form used with VAM_CONV_PS2   */
   VAM_PACK_PS2 = 2,      /* src OIHW with O = Cq*4 in PixelShuffle order (c*4+i*2+j) ->
                             packed n = (i*2+j)*Cq + c   (layers/layers.py:82-86)          */
-  VAM_PACK_GDN = 3       /* src gamma [N][Cin] in reparametrised storage -> max(g,2^-18)^2-2^-36
+  VAM_PACK_GDN = 3,      /* src gamma [N][Cin] in reparametrised storage -> max(g,2^-18)^2-2^-36
                             (layers/gdn.py:52-66, compressai NonNegativeParametrizer)     */
+  VAM_PACK_CONV_DGRAD = 4/* weights of the DATA-GRADIENT conv of a stride-1 nn.Conv2d: src is the forward
+                            OIHW tensor [Cout][Cin][kh][kw]; call with cin = Cout, n = Cin (taps flipped,
+                            channel roles swapped) — what autograd's conv backward-data computes          */
 };
 /* Device-side repack of a weight tensor into the kernel's [tap][k-chunk][n][k] layout. */
 int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase,
@@ -189,6 +192,12 @@ int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int l
 int vam_eb_forward(const float* z, int ld_z, const float* params, int C,
                    float* zhat, int ld_zhat, float* lik, int ld_lik, int32_t* sym, int ld_sym,
                    double* log2sum, int pix_per_item, long n_pix, void* stream);
+/* Training variant: z_hat is still round(z-med)+med (pic.py:282-284) but the likelihood is evaluated at
+ * z + noise (additive-uniform proxy, entropy_models.py:132-138,471-473).  noise == NULL: identical to
+ * vam_eb_forward. */
+int vam_eb_forward_noise(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat,
+                         float* lik, int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item,
+                         long n_pix, const float* noise, int ld_noise, void* stream);
 /* EntropyModel.dequantize (entropy_models.py:161-168): out = float(sym) + mu (mu may be NULL). */
 int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, float* out, int ld_out,
                    long n_pix, int C, void* stream);
@@ -200,6 +209,26 @@ int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int 
 int vam_memset_zero(void* ptr, size_t bytes, void* stream);
 /* sum((a-b)^2) accumulated in double into acc[0] (PSNR, utility/functions.py:172-174) */
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
+
+/* ------------------------------------------------------------------ REM fine-tune backward (configs[4]) */
+/* Weight gradient of a stride-1, pad k/2 convolution (autograd's conv backward-weight for layers/rem.py:40-49):
+ * dw[n][c_off + c][ty][tx] = sum_p dy[p][n] * x[pix(p)+(ty-k/2, tx-k/2)][c], OIHW with `cin_total` input
+ * channels; x is a C-channel window (one segment of a concatenated input lands at c_off). Fixed summation order. */
+int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw,
+                   int C, int N, float* dw_oihw, int cin_total, int c_off, void* stream);
+/* out[n] = sum_p dy[p][n]  (bias gradient) */
+int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream);
+/* dx = dy * (act > 0 ? 1 : 0.01): LeakyReLU(0.01) backward from its OUTPUT (same sign as its input) */
+int vam_leaky_bwd(const float* act, int ld_a, const float* dy, int ld_dy, float* dx, int ld_dx, long n_pix, int C, void* stream);
+int vam_mul(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, long n_pix, int C, void* stream);
+/* Training-mode Gaussian likelihood (entropy_models.py:132-138,620-652; pic.py:437-442): v = ((y-y2)-mu)*m + noise,
+ * s = max(sigma*m, .11), lik = max(Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), 1e-9).  grad_lik == NULL: forward (writes lik).
+ * grad_lik != NULL: backward (writes dmu, dsigma = grad_lik * dlik/d{mu,sigma}, with compressai's LowerBound
+ * gradient rule on both bounds).  y2 / mask may be NULL. */
+int vam_gauss_train(const float* y, int ld_y, const float* y2, int ld_y2, const float* mu, int ld_mu,
+                    const float* sigma, int ld_sigma, const float* mask, int ld_mask, const float* noise, int ld_noise,
+                    const float* grad_lik, int ld_glik, float* lik, int ld_lik, float* dmu, int ld_dmu,
+                    float* dsigma, int ld_dsigma, long n_pix, int C, void* stream);
 
 /* ------------------------------------------------------------------ bitstream (HOST pointers) */
 /* compressai `_CXX.pmf_to_quantized_cdf` (reference entropy_models.py:61-64): n probabilities ->

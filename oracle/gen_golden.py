@@ -139,6 +139,54 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "forward_single_quality.npz"), **rec)
     with open(os.path.join(GOLD, "forward_single_quality.json"), "w") as f:
         json.dump(scal, f, indent=1)
+    # 6. REM fine-tune step: the reference's own training-mode forward + RateLoss + backward
+    #    (training/step.py:62-88 with --training_type rems, train.py:223-226).  Its additive noise comes from
+    #    Tensor.uniform_; for the duration of the call that method is replaced by a deterministic source
+    #    (vampic.synth.uniform, host-independent) so the same draws can be injected on the other side.
+    import importlib.util          # training/__init__.py pulls torchvision (absent): load loss.py on its own
+    spec = importlib.util.spec_from_file_location("ref_training_loss", os.path.join(REF, "training", "loss.py"))
+    loss_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loss_mod)
+    RateLoss = loss_mod.RateLoss
+    net.train()
+    net.freeze_all()
+    net.unfreeze_rems()
+    x = synth.synth_image(1, 64, 128, seed=0)
+    ny = synth.uniform((1, 640, 4, 8), 101) - 0.5
+    nz = synth.uniform((1, 192, 1, 2), 102) - 0.5
+    queue = [nz.transpose(0, 1).reshape(192, 1, -1)] + list(ny.chunk(20, 1))
+    real_uniform = torch.Tensor.uniform_
+
+    def fake_uniform(self, a=0.0, b=1.0):
+        src = queue.pop(0)
+        assert tuple(src.shape) == tuple(self.shape) and (a, b) == (-0.5, 0.5), (src.shape, self.shape, a, b)
+        with torch.no_grad():
+            return self.copy_(src)
+
+    torch.Tensor.uniform_ = fake_uniform
+    try:
+        o = net.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck.clone())
+    finally:
+        torch.Tensor.uniform_ = real_uniform
+    assert not queue
+    crit = RateLoss()(o, x)
+    crit["loss"].backward()
+    rec = {"lik_y": o["likelihoods"]["y"].detach().numpy(), "lik_z": o["likelihoods"]["z"].detach().numpy(),
+           "loss": np.array([crit["loss"].item(), crit["bpp_loss"].item(), crit["bpp_hype"].item()], dtype=np.float64)}
+    names, norms, samples = [], [], []
+    for k, p_ in net.post_latent[0].named_parameters():
+        gflat = p_.grad.detach().reshape(-1)
+        names.append(k)
+        norms.append(gflat.double().norm().item())
+        samples.append(gflat[::53].numpy())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms, dtype=np.float64)
+    rec["grad_samples"] = np.concatenate(samples).astype(np.float32)      # every 53rd element of each gradient
+    others = [k for k, p_ in net.named_parameters() if p_.grad is not None and not k.startswith("post_latent.")]
+    assert not others, others
+    np.savez_compressed(os.path.join(GOLD, "rem_train_step.npz"), **rec)
+    net.eval()
+
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):
         print(f"  {fn}: {os.path.getsize(os.path.join(GOLD, fn)) / 1024:.1f} KiB")

@@ -503,3 +503,115 @@ def bpp(likelihoods: dict, num_pixels: int) -> float:
 
 def log2_sum_per_image(lik: Tensor) -> Tensor:
     return torch.log2(lik.double()).flatten(1).sum(1)
+
+
+# --------------------------------------------------------------------------
+# A.9 REM fine-tune step (BASELINE configs[4]): training-mode forward + autograd
+#     (models/rem_pic.py:229-422 with training=True, training/step.py:56-95, training/loss.py:189-229)
+# --------------------------------------------------------------------------
+class _LowerBoundFn(torch.autograd.Function):
+    """compressai.ops.LowerBound (1.2.4, published definition): max(x, bound); the gradient passes where
+    x >= bound or where it would push x up (grad < 0)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)).to(g.dtype) * g, None
+
+
+def lower_bound(x: Tensor, bound: float) -> Tensor:
+    return _LowerBoundFn.apply(x, torch.tensor([float(bound)]))
+
+
+def gaussian_likelihood_noise(inputs: Tensor, scales: Tensor, means: Optional[Tensor], noise: Tensor) -> Tensor:
+    """Training-mode ``GaussianConditional.forward`` (entropy_models.py:637-652 with quantize "noise" :132-138)."""
+    outputs = inputs + noise
+    values = outputs - means if means is not None else outputs
+    s = lower_bound(scales, SCALE_BOUND)
+    values = values.abs()
+    lik = _phi_c((0.5 - values) / s) - _phi_c((-0.5 - values) / s)
+    return lower_bound(lik, LIKELIHOOD_BOUND)
+
+
+def eb_likelihood_noise(sd: SD, z: Tensor, noise: Tensor, prefix: str = "entropy_bottleneck.") -> Tensor:
+    """Training-mode ``EntropyBottleneck.forward`` likelihood: evaluated at z + noise (entropy_models.py:471-478)."""
+    B, C = z.shape[:2]
+    out = (z + noise).transpose(0, 1).contiguous().reshape(C, 1, -1)
+    lower = eb_logits_cumulative(sd, out - 0.5, prefix)
+    upper = eb_logits_cumulative(sd, out + 0.5, prefix)
+    sign = -torch.sign(lower + upper)
+    lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    lik = torch.clamp_min(lik, LIKELIHOOD_BOUND)
+    return lik.reshape((C, B) + tuple(z.shape[2:])).transpose(0, 1).contiguous()
+
+
+def rem_training_step(sd: SD, x: Tensor, quality: float, checkpoint_ref: Tensor, noise_y: Tensor, noise_z: Tensor, *,
+                      check_levels: Sequence[float], div: int = 320, chunk: int = 32, max_support: int = 5,
+                      prog_support: int = 5) -> dict:
+    """One REM fine-tune step's forward + backward: returns the training-mode likelihoods, RateLoss's bpp and
+    dLoss/d(post_latent.<r>.*) by autograd.  Everything outside the REM is frozen (train.py:223-226), so it is
+    evaluated without a graph; masks carry no gradient (hard comparison)."""
+    assert quality > check_levels[0]
+    ri = rem_index(check_levels, quality)
+    pre = f"post_latent.{ri}."
+    names = [k for k in sd if k.startswith(pre)]
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    sdt = dict(sd)
+    sdt.update(leaves)
+    ns0 = div // chunk
+    with torch.no_grad():
+        y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)
+        z = h_a(sd, y)
+        means_h, scales_h, _, z_hat = compute_hyperprior(sd, y, quality)
+        z_lik = eb_likelihood_noise(sd, z, noise_z)
+        ys = y.chunk(y.shape[1] // chunk, 1)
+        nys = noise_y.chunk(y.shape[1] // chunk, 1)
+        yhat_b, lik, mu_b, std_b = [], [], [], []
+        for i in range(ns0):
+            sup = yhat_b[:min(max_support, i)]
+            msup = torch.cat([means_h[:, :div]] + sup, 1)
+            ssup = torch.cat([scales_h[:, :div]] + sup, 1)
+            mu = cc_stack(sd, f"cc_mean_transforms.{i}.", msup)
+            sc = cc_stack(sd, f"cc_scale_transforms.{i}.", ssup)
+            mu_b.append(mu)
+            std_b.append(sc)
+            lik.append(gaussian_likelihood_noise(ys[i], sc, mu, nys[i]))
+            yh = torch.round(ys[i] - mu) + mu
+            lrp = cc_stack(sd, f"lrp_transforms.{i}.", torch.cat([msup, yh], 1))
+            yhat_b.append(yh + 0.5 * torch.tanh(lrp))
+    ck = checkpoint_ref.chunk(10, 1)
+    mu_tot, std_tot, masks, mu_f, std_f = [], [], [], [], []
+    for j in range(ns0):
+        with torch.no_grad():
+            r = ys[ns0 + j] - ys[j]
+            s = min(prog_support, j)
+            msup = torch.cat([means_h[:, div:], yhat_b[j]] + mu_tot[j - s:j], 1)
+            ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + std_tot[j - s:j], 1)
+            mu = cc_stack(sd, f"cc_mean_transforms_prog.{j}.", msup)
+            sc = cc_stack(sd, f"cc_scale_transforms_prog.{j}.", ssup)
+            mu_tot.append(mu + yhat_b[j])
+            std_tot.append(sc)
+            att = variance_mask(sc, quality)
+            att = torch.cat([att, att], 1)
+        ep = rem_block(sdt, f"{pre}{j}.", ck[j], torch.cat([mu_b[j], std_b[j]], 1), torch.cat([mu, sc], 1), att)
+        mu2, sc2 = ep.chunk(2, 1)
+        m = variance_mask(sc2.detach(), quality)
+        masks.append(m)
+        mu_f.append(mu2)
+        std_f.append(sc2)
+        lik.append(gaussian_likelihood_noise((r - mu2) * m, sc2 * m, None, nys[ns0 + j]))
+    lik_y = torch.cat(lik, 1)
+    num_pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    den = -math.log(2) * num_pixels
+    bpp_y = torch.log(lik_y).sum() / den
+    bpp_z = torch.log(z_lik).sum() / den
+    loss = bpp_y + bpp_z
+    loss.backward()
+    return {"likelihoods": {"y": lik_y.detach(), "z": z_lik}, "loss": float(loss.detach()),
+            "grads": {k: v.grad for k, v in leaves.items()}, "mask": torch.cat(masks, 1),
+            "mu": torch.cat(mu_f, 1).detach(), "std": torch.cat(std_f, 1).detach()}

@@ -1,0 +1,241 @@
+"""REM fine-tune path (BASELINE configs[4], reference train.py:223-226 + training/step.py:56-95) on the GPU:
+backward kernels against torch autograd / the oracle, the full step against the reference's own gradients."""
+import copy
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import vampic                              # noqa: E402
+import vampic.synth as synth               # noqa: E402
+import vampic_oracle as O                  # noqa: E402
+from vampic import _lib as L               # noqa: E402
+from vampic import ops                     # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("k,segs,n,hw", [(3, (32, 32), 32, (16, 16)), (1, (32, 32, 32), 64, (4, 8)), (3, (64,), 64, (5, 7)),
+                                         (3, (32,), 32, (16, 24))])
+def test_conv_backward_matches_autograd(k, segs, n, hw):
+    """Data gradient (conv kernel on VAM_PACK_CONV_DGRAD weights) and weight / bias gradients (vam_conv_wgrad,
+    vam_colsum) of a stride-1 conv over a virtual channel concat.  Tolerance 2e-5 of the max (fp32, different
+    summation order than ATen)."""
+    B, (H, W) = 2, hw
+    cin = sum(segs)
+    w = synth.normal((n, cin, k, k), 1, 0.1)
+    b = synth.normal((n,), 2, 0.1)
+    xs = [synth.normal((B, c, H, W), 3 + i) for i, c in enumerate(segs)]
+    dy = synth.normal((B, n, H, W), 9)
+    x = torch.cat(xs, 1).requires_grad_(True)
+    wt, bt = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(x, wt, bt, padding=k // 2).backward(dy)
+    xv = [ops.from_nchw(t.cuda()) for t in xs]
+    dyv = ops.from_nchw(dy.cuda())
+    dw = torch.full((n, cin, k, k), float("nan"), device="cuda")
+    db = torch.full((n,), float("nan"), device="cuda")
+    ops.conv_wgrad(xv, dyv, dw, db)
+    assert _rel(dw, wt.grad) <= 2e-5 and _rel(db, bt.grad) <= 2e-5
+    pk = ops.pack_conv_dgrad(w.cuda())
+    dx = ops.new_view(B, H, W, cin)
+    ops.conv_group([ops.conv_problem(pk, [dyv], dx)])
+    assert _rel(dx.torch_nchw(), x.grad) <= 2e-5
+
+
+def test_leaky_bwd_and_mul():
+    a = synth.normal((2, 32, 4, 8), 1)
+    g = synth.normal((2, 32, 4, 8), 2)
+    act = F.leaky_relu(a, 0.01)
+    av, gv = ops.from_nchw(act.cuda()), ops.from_nchw(g.cuda())
+    o = ops.new_view(2, 4, 8, 32)
+    ops.leaky_bwd(av, gv, o)
+    assert torch.equal(o.torch_nchw().cpu(), g * torch.where(a > 0, 1.0, 0.01).float())
+    ops.mul(av, gv, o)
+    assert torch.equal(o.torch_nchw().cpu(), act * g)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_gauss_train_matches_oracle_autograd(masked):
+    """Noisy likelihood forward (<= 1e-6 absolute: erfc implementations and the division differ by an ulp, sigma down to 0.11) and its gradient w.r.t. (mu, sigma)
+    incl. both LowerBound rules (sigma below 0.11, likelihood below 1e-9) against the oracle's autograd."""
+    shp = (2, 64, 8, 8)
+    y, y2 = synth.normal(shp, 1, 4.0), synth.normal(shp, 2, 2.0)
+    mu = synth.normal(shp, 3, 2.0).requires_grad_(True)
+    sg = (synth.synth_sigma(2, 64 * 64, seed=4).reshape(shp) * 0.5).requires_grad_(True)   # some below the 0.11 bound
+    with torch.no_grad():
+        y[0, 0, 0, :4] += 80.0                                                              # likelihood below 1e-9
+    nz = synth.uniform(shp, 5) - 0.5
+    m = (synth.uniform(shp, 6) > 0.4).float()
+    g = synth.normal(shp, 7)                                   # both signs: exercises the (grad < 0) pass-through
+    if masked:
+        lik = O.gaussian_likelihood_noise(((y - y2) - mu) * m, sg * m, None, nz)
+    else:
+        lik = O.gaussian_likelihood_noise(y, sg, mu, nz)
+    lik.backward(g)
+    V = lambda t: ops.from_nchw(t.detach().cuda())
+    lk, dmu, dsg = ops.new_view(2, 8, 8, 64), ops.new_view(2, 8, 8, 64), ops.new_view(2, 8, 8, 64)
+    kw = dict(y2=V(y2), mask=V(m)) if masked else {}
+    ops.gauss_train(V(y), V(mu), V(sg), V(nz), lik=lk, **kw)
+    ops.gauss_train(V(y), V(mu), V(sg), V(nz), grad_lik=V(g), dmu=dmu, dsigma=dsg, **kw)
+    assert float((lk.torch_nchw().cpu() - lik.detach()).abs().max()) <= 1e-6
+    for got, ref in ((dmu, mu.grad), (dsg, sg.grad)):
+        d = (got.torch_nchw().cpu() - ref).abs()
+        assert float(d.max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, float(d.max())
+    assert float((sg.grad == 0).float().mean()) > 0.01       # the bounds did clip some gradients
+
+
+def test_rem_blocks_backward_teacher_forced():
+    """Taped REM forward + backward lowering (engine.lower_rem_blocks_train / lower_rem_backward) on IDENTICAL
+    inputs against autograd over the oracle's rem_block: outputs 1e-5, every parameter gradient 2e-5 of its max."""
+    from vampic import engine as E, layers as Ly
+    K, N, B, H, W = 2, 32, 2, 8, 8
+    mods = [Ly.LatentRateReduction(N, True, "middle") for _ in range(K)]
+    sds = []
+    for k, mod in enumerate(mods):
+        sd = synth.synth_state_dict(mod.state_dict(), 11 + k)
+        mod.load_state_dict(sd)
+        mod.cuda()
+        sds.append(sd)
+    plan, bw = E.Plan("cuda"), E.Plan("cuda")
+    V = lambda t: ops.from_nchw(t.cuda())
+    yck = [synth.normal((B, N, H, W), 20 + k, 3.0) for k in range(K)]
+    epb = [synth.normal((B, 2 * N, H, W), 30 + k) for k in range(K)]
+    epp = [synth.normal((B, 2 * N, H, W), 40 + k) for k in range(K)]
+    att = [(synth.uniform((B, N, H, W), 50 + k) > 0.5).float() for k in range(K)]
+    dres = [synth.normal((B, 2 * N, H, W), 60 + k) for k in range(K)]
+    vb, vp, va, vd = [V(t) for t in epb], [V(t) for t in epp], [V(t) for t in att], [V(t) for t in dres]
+    outs = [ops.new_view(B, H, W, 2 * N) for _ in range(K)]
+    packs = E.TrainPacks(*E.rem_trained_convs(mods))
+    packs.record_refresh(plan)
+    tape = E.lower_rem_blocks_train(plan, mods, [V(t) for t in yck], [[v.window(0, N), v.window(N, N)] for v in vb],
+                                    [[v.window(0, N), v.window(N, N)] for v in vp], va,
+                                    [[o.window(0, N), o.window(N, N)] for o in outs], packs)
+    grads = {id(p): torch.full_like(p, float("nan")) for mod in mods for p in mod.parameters()}
+    E.lower_rem_backward(bw, tape, mods, [v.window(0, N) for v in vd], [v.window(N, N) for v in vd], va, packs, grads)
+    plan.run()
+    bw.run()
+    torch.cuda.synchronize()
+    for k in range(K):
+        leaves = {"r." + n: t.clone().requires_grad_(True) for n, t in sds[k].items()}
+        res = O.rem_block(leaves, "r.", yck[k], epb[k], epp[k], torch.cat([att[k], att[k]], 1))
+        res.backward(dres[k])
+        assert _rel(outs[k].torch_nchw(), res) <= 1e-5
+        for n, p in mods[k].named_parameters():
+            assert _rel(grads[id(p)], leaves["r." + n].grad) <= 2e-5, (k, n)
+
+
+def _rate_loss(out, x):
+    """training/loss.py:196-229 (RateLoss): bpp of y + z."""
+    den = -math.log(2) * x.shape[0] * x.shape[2] * x.shape[3]
+    return torch.log(out["likelihoods"]["y"]).sum() / den + torch.log(out["likelihoods"]["z"]).sum() / den
+
+
+@pytest.fixture(scope="module")
+def train_model(gpu_model):
+    net, sd = gpu_model
+    m = copy.deepcopy(net)
+    m.train()
+    m.freeze_all()
+    m.unfreeze_rems()
+    return m, sd
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rem_train_step_matches_reference_gradients(train_model, use_graph):
+    """One fine-tune step (forward in training mode with the fixture's noise, RateLoss, backward) against the
+    gradients the REFERENCE computed on a CPU (tests/golden/rem_train_step.npz).  The frozen front end feeds
+    (mu, sigma) that differ from the CPU's by fp32 summation order (~1e-5 of their range), and the noisy
+    likelihood is a smooth but steep function of them (sigma >= 0.11), so the end-to-end bounds are: likelihoods
+    5e-4 absolute, loss 1e-5 relative.  Gradients additionally pass through hard gates (LowerBound's pass-through
+    rule at sigma = 0.11, LeakyReLU's sign) that an fp32-order difference can flip for single elements, so they are
+    bounded in aggregate: all sampled gradient entries together within 1e-3 of their joint norm, each tensor within
+    3e-2 of its own norm.  The backward machinery itself is held to 2e-5 by
+    test_rem_blocks_backward_teacher_forced and test_conv_backward_matches_autograd."""
+    m, _ = train_model
+    m.use_graph = use_graph
+    gold = np.load(os.path.join(GOLD, "rem_train_step.npz"))
+    ck = torch.from_numpy(np.load(os.path.join(GOLD, "forward_single_quality.npz"))["rem_ck"]).cuda()
+    x = synth.synth_image(1, 64, 128, seed=0).cuda()
+    noise = {"y": synth.uniform((1, 640, 4, 8), 101) - 0.5, "z": synth.uniform((1, 192, 1, 2), 102) - 0.5}
+    for rep in range(2):                                      # second pass replays the captured graphs
+        m.zero_grad(set_to_none=True)
+        out = m.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck, noise=noise)
+        loss = _rate_loss(out, x)
+        loss.backward()
+        e_y = _rel(out["likelihoods"]["y"], torch.from_numpy(gold["lik_y"]))
+        e_z = _rel(out["likelihoods"]["z"], torch.from_numpy(gold["lik_z"]))
+        e_l = abs(float(loss.detach()) - gold["loss"][0]) / gold["loss"][0]
+        print(f"lik_y err {e_y:.2e}  lik_z err {e_z:.2e}  loss rel err {e_l:.2e}")
+        assert e_y <= 5e-4 and e_z <= 1e-5 and e_l <= 1e-5
+        samples, off, worst, num, den = gold["grad_samples"], 0, 0.0, 0.0, 0.0
+        params = dict(m.post_latent[0].named_parameters())
+        for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+            g = params[str(name)].grad.reshape(-1).cpu()
+            s = g[::53].numpy()
+            ref = samples[off:off + len(s)]
+            off += len(s)
+            assert abs(float(g.double().norm()) - norm) <= 3e-2 * norm, name
+            err = float(np.abs(s - ref).max()) / (norm + 1e-30)
+            worst = max(worst, err)
+            num += float(((s - ref).astype(np.float64) ** 2).sum())
+            den += float((ref.astype(np.float64) ** 2).sum())
+            assert err <= 3e-2, (name, err)
+        print(f"gradients: joint relative error {(num / den) ** 0.5:.2e}, worst tensor {worst:.2e}")
+        assert (num / den) ** 0.5 <= 1e-3
+        assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("post_latent."))
+    print(f"worst gradient error / norm: {worst:.2e}")
+
+
+def test_rem_finetune_loop_reduces_rate(train_model):
+    """The reference's loop shape (training/step.py:56-95): checkpoint under no_grad, training forward, RateLoss,
+    backward, clip, Adam.  The rate on a fixed batch must go down, the eval plan must see the new weights, and
+    nothing outside post_latent may move."""
+    m0, _ = train_model
+    m = copy.deepcopy(m0)
+    m.use_graph = True
+    x = synth.synth_image(2, 64, 128, seed=3).cuda()
+    noise = {"y": (synth.uniform((2, 640, 4, 8), 7) - 0.5).cuda(), "z": (synth.uniform((2, 192, 1, 2), 8) - 0.5).cuda()}
+    frozen = {n: p.detach().clone() for n, p in m.named_parameters() if not n.startswith("post_latent.")}
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    with torch.no_grad():
+        ck = m.ExtractChekpointRepr(x, quality=0.75, rc=False)
+        before = m.forward_single_quality(x, quality=2.5, training=False, checkpoint_ref=ck)["likelihoods"]["y"].clone()
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck, noise=noise)
+        loss = _rate_loss(out, x)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("fine-tune losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]
+    with torch.no_grad():
+        after = m.forward_single_quality(x, quality=2.5, training=False, checkpoint_ref=ck)["likelihoods"]["y"]
+    assert not torch.equal(before, after)                     # cached eval plan was rebuilt on the new weights
+    for n, p in m.named_parameters():
+        if not n.startswith("post_latent."):
+            assert torch.equal(p, frozen[n]), n
+    # random noise path (the reference's uniform_): finite, differentiable
+    out = m.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck)
+    assert out["likelihoods"]["y"].requires_grad and torch.isfinite(out["likelihoods"]["y"]).all()
+
+
+def test_training_outside_rem_fails_loudly(train_model):
+    m0, _ = train_model
+    m = copy.deepcopy(m0)
+    m.unfreeze_decoder()
+    x = synth.synth_image(1, 64, 64, seed=0).cuda()
+    with pytest.raises(NotImplementedError):
+        m.forward_single_quality(x, quality=2.5, training=True)

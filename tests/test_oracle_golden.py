@@ -111,3 +111,28 @@ def test_forward_single_quality_matches_reference(synth_model_cpu):
     _close(o["x_hat"], gold["rem_x_hat"])
     _close(o["y_hat"], gold["rem_y_hat"])
     _close(o["likelihoods"]["y"], gold["rem_lik_y"])
+
+
+def test_rem_training_step_matches_reference(synth_model_cpu):
+    """Training-mode forward + RateLoss + backward of the REM fine-tune step (BASELINE configs[4]) against the
+    reference's own autograd run (oracle/gen_golden.py §6): likelihoods, loss and every REM gradient."""
+    _, sd = synth_model_cpu
+    gold = np.load(os.path.join(GOLD, "rem_train_step.npz"))
+    ck = torch.from_numpy(np.load(os.path.join(GOLD, "forward_single_quality.npz"))["rem_ck"])
+    x = synth.synth_image(1, 64, 128, seed=0)
+    ny = synth.uniform((1, 640, 4, 8), 101) - 0.5
+    nz = synth.uniform((1, 192, 1, 2), 102) - 0.5
+    o = O.rem_training_step(sd, x, 2.5, ck, ny, nz, check_levels=[0.75])
+    _close(o["likelihoods"]["y"], gold["lik_y"])
+    _close(o["likelihoods"]["z"], gold["lik_z"])
+    assert abs(o["loss"] - gold["loss"][0]) <= 1e-6 * abs(gold["loss"][0])
+    samples, off = gold["grad_samples"], 0
+    assert len(gold["grad_names"]) == len(o["grads"]) == 420
+    for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+        g = o["grads"]["post_latent.0." + str(name)].reshape(-1)
+        s = g[::53].numpy()
+        ref = samples[off:off + len(s)]
+        off += len(s)
+        assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
+        assert np.abs(s - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-10, name
+    assert off == len(samples)
