@@ -29,6 +29,16 @@ class VamSeg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("ld", C.c_int32)]
 
 
+VAM_MAX_WGRAD_GROUP = 16
+
+
+class VamWgrad(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("ld_x", C.c_int), ("ld_dy", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("C", C.c_int), ("N", C.c_int),
+                ("cin_total", C.c_int), ("c_off", C.c_int)]
+
+
 class VamAux(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("pad_", C.c_int32)]
 
@@ -81,7 +91,8 @@ _SIGNATURES = {
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vam_sqdiff_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_eb_forward_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),
-    "vam_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vam_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vam_conv_wgrad_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vam_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "vam_leaky_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),

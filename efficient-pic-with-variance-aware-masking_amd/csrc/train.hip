@@ -17,44 +17,81 @@ namespace vam {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // dW[n][c_off + c][ty][tx] = sum_p dY[p][n] * X[pix(p) + (ty - pad, tx - pad)][c]      (stride 1)
-// grid = (taps, N/32 tiles, C/32 tiles); 4 waves split the pixels, fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
-                                                    int ld_dy, int B, int H, int W, int kh, int kw, int pad_y, int pad_x,
-                                                    int C, int N, float* __restrict__ dw, int cin_total, int c_off) {
-  __shared__ float red[4][32][33];
-  const int tap = blockIdx.x, n0 = blockIdx.y * 32, c0 = blockIdx.z * 32;
-  const int ty = tap / kw, tx = tap % kw;
+// grid = (taps * N/32 tiles * C/32 tiles [max over the group], problems).  8 waves split the pixels in batches of
+// 32 (16 MFMAs with all 32 loads of a batch in flight: the loop is latency-bound otherwise); fixed-order LDS
+// reduction.  The block of tap 0 / channel tile 0 / c_off 0 also produces db[n] = sum_p dY[p][n].
+constexpr int WG_WAVES = 8, WG_BATCH = 16;   // MFMAs per batch; each covers 2 pixels
+
+struct WgradArgs {
+  vam_wgrad p[VAM_MAX_WGRAD_GROUP];
+};
+
+__global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs args) {
+  __shared__ float red[WG_WAVES][32][33];
+  __shared__ float redb[WG_WAVES][2][32];
+  const vam_wgrad& pr = args.p[blockIdx.y];
+  const int kh = pr.kh, kw = pr.kw, taps = kh * kw;
+  const int n_tiles = (pr.N + 31) / 32, c_tiles = (pr.C + 31) / 32;
+  int bid = blockIdx.x;
+  if (bid >= taps * n_tiles * c_tiles) return;
+  const int tap = bid % taps;
+  bid /= taps;
+  const int n0 = (bid % n_tiles) * 32, c0 = (bid / n_tiles) * 32;
+  const int ty = tap / kw, tx = tap % kw, pad_y = kh / 2, pad_x = kw / 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const long P = (long)B * H * W;
-  const int HW = H * W;
-  const bool n_ok = n0 + l31 < N, c_ok = c0 + l31 < C;
+  const int H = pr.H, W = pr.W, HW = H * W;
+  const long P = (long)pr.B * HW;
+  const float* __restrict__ x = pr.x;
+  const float* __restrict__ dy = pr.dy;
+  const int ld_x = pr.ld_x, ld_dy = pr.ld_dy;
+  const bool n_ok = n0 + l31 < pr.N, c_ok = c0 + l31 < pr.C;
+  const bool want_db = pr.db != nullptr && tap == 0 && c0 == 0 && pr.c_off == 0;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // A[i = n][k = pixel], B[k = pixel][j = c]: lane (l31, lh) feeds pixel p + lh of each MFMA
-  for (long p = (long)wid * 2 + lh; p < P + 1; p += 8) {
-    float a = 0.f, b = 0.f;
-    if (p < P) {
-      if (n_ok) a = dy[p * ld_dy + n0 + l31];
-      const int bi = (int)(p / HW);
-      const int r = (int)(p - (long)bi * HW);
-      const int oy = r / W, ox = r - oy * W;
-      const int iy = oy - pad_y + ty, ix = ox - pad_x + tx;
-      if (c_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        b = x[((long)bi * HW + (long)iy * W + ix) * ld_x + c0 + l31];
+  float bsum = 0.f;
+  for (long pb = (long)wid * (2 * WG_BATCH); pb < P; pb += (long)WG_WAVES * 2 * WG_BATCH) {
+    float a[WG_BATCH], b[WG_BATCH];
+#pragma unroll
+    for (int i = 0; i < WG_BATCH; ++i) {
+      const long p = pb + 2 * i + lh;
+      a[i] = 0.f;
+      b[i] = 0.f;
+      if (p < P) {
+        if (n_ok) a[i] = dy[p * ld_dy + n0 + l31];
+        const int bi = (int)(p / HW);
+        const int r = (int)(p - (long)bi * HW);
+        const int oy = r / W, ox = r - oy * W;
+        const int iy = oy - pad_y + ty, ix = ox - pad_x + tx;
+        if (c_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          b[i] = x[((long)bi * HW + (long)iy * W + ix) * ld_x + c0 + l31];
+      }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WG_BATCH; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+      bsum += a[i];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
+  redb[wid][lh][l31] = bsum;
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+  for (int i = threadIdx.x; i < 32 * 32; i += WG_WAVES * 64) {
     const int n = i >> 5, c = i & 31;
-    if (n0 + n < N && c0 + c < C) {
-      const float v = ((red[0][n][c] + red[1][n][c]) + red[2][n][c]) + red[3][n][c];
-      dw[(((long)(n0 + n) * cin_total + c_off + c0 + c) * kh + ty) * kw + tx] = v;
+    if (n0 + n < pr.N && c0 + c < pr.C) {
+      float v = red[0][n][c];
+#pragma unroll
+      for (int k = 1; k < WG_WAVES; ++k) v += red[k][n][c];
+      pr.dw[(((long)(n0 + n) * pr.cin_total + pr.c_off + c0 + c) * kh + ty) * kw + tx] = v;
     }
+  }
+  if (want_db && threadIdx.x < 32 && n0 + threadIdx.x < pr.N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < WG_WAVES; ++k) v += redb[k][0][threadIdx.x] + redb[k][1][threadIdx.x];
+    pr.db[n0 + threadIdx.x] = v;
   }
 }
 
@@ -178,16 +215,33 @@ using namespace vam;
 
 extern "C" {
 
-int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw, int C,
-                   int N, float* dw, int cin_total, int c_off, void* stream) {
-  VAM_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C > 0 && N > 0, "vam_conv_wgrad: bad arguments");
-  VAM_REQUIRE((kh == 1 || kh == 3 || kh == 5) && kw == kh, "vam_conv_wgrad: square odd kernels (stride 1, pad k/2)");
-  VAM_REQUIRE(c_off >= 0 && c_off + C <= cin_total && ld_x >= C && ld_dy >= N, "vam_conv_wgrad: channel window");
-  dim3 grid(kh * kw, cdiv(N, 32), cdiv(C, 32));
-  ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, 2.0 * B * H * W * (double)C * N * kh * kw, 0);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ld_x, dy, ld_dy, B, H, W, kh, kw, kh / 2,
-                     kw / 2, C, N, dw, cin_total, c_off);
+int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
+  VAM_REQUIRE(probs && n_probs >= 1 && n_probs <= VAM_MAX_WGRAD_GROUP, "vam_conv_wgrad_group: 1..%d problems", VAM_MAX_WGRAD_GROUP);
+  int max_blocks = 0;
+  double flops = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    const vam_wgrad& p = probs[i];
+    VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
+    VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (stride 1, pad k/2)");
+    VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
+    int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
+    max_blocks = nb > max_blocks ? nb : max_blocks;
+    flops += 2.0 * p.B * p.H * p.W * (double)p.C * p.N * p.kh * p.kw;
+  }
+  WgradArgs wa;
+  for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
+  ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
   return check_launch("wgrad_kernel");
+}
+
+int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw, int C,
+                   int N, float* dw, float* db, int cin_total, int c_off, void* stream) {
+  vam_wgrad p;
+  p.x = x; p.dy = dy; p.dw = dw; p.db = db;
+  p.ld_x = ld_x; p.ld_dy = ld_dy; p.B = B; p.H = H; p.W = W; p.kh = kh; p.kw = kw; p.C = C; p.N = N;
+  p.cin_total = cin_total; p.c_off = c_off;
+  return vam_conv_wgrad_group(&p, 1, stream);
 }
 
 int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream) {

@@ -65,6 +65,21 @@ class Plan:
             self.branch_of.append(self.cur_branch)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
+    def wgrad(self, problems: Sequence[L.VamWgrad]):
+        """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`)."""
+        lib = L.load()
+        for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
+            chunk = list(problems[i:i + L.VAM_MAX_WGRAD_GROUP])
+            arr = (L.VamWgrad * len(chunk))(*chunk)
+            n = len(chunk)
+            self.keep.append(arr)
+            fl = sum(2.0 * c.B * c.H * c.W * c.C * c.N * c.kh * c.kw for c in chunk)
+            self.flops += fl
+            self.meta.append({"kind": "wgrad", "flops": fl, "desc": f"{n}x wgrad [{chunk[0].C}->{chunk[0].N} k{chunk[0].kh}]"})
+            self.branch_of.append(self.cur_branch)
+            self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_wgrad_group(arr, n, ops.stream_ptr()),
+                                                           "vam_conv_wgrad_group"))
+
     def call(self, fn: Callable[[], None], desc: str = "op"):
         self.meta.append({"kind": "op", "flops": 0.0, "desc": desc})
         self.branch_of.append(self.cur_branch)
@@ -472,19 +487,23 @@ def _rb_backward(plan: Plan, recs, d_outs, need_dx: bool, packs: TrainPacks, gra
     layout).  Returns dL/dx per block (one View over the concatenated input channels) or None."""
     g = lambda p: grads[id(p)]
     dh2 = [plan.buf(r["o2"].B, r["o2"].H, r["o2"].W, r["o2"].C) for r in recs]
+    wg = []
     for r, do, t in zip(recs, d_outs, dh2):
         plan.call(lambda r=r, do=do, t=t: ops.leaky_bwd(r["o2"], do, t), "leaky bwd")
         b = r["block"]
-        plan.call(lambda r=r, t=t, b=b: ops.conv_wgrad([r["h1a"]], t, g(b.conv2.weight), g(b.conv2.bias)), "wgrad conv2")
+        wg += ops.wgrad_problems([r["h1a"]], t, g(b.conv2.weight), g(b.conv2.bias))
+    plan.wgrad(wg)
     dh1a = [plan.buf(r["h1a"].B, r["h1a"].H, r["h1a"].W, r["h1a"].C) for r in recs]
     plan.conv([ops.conv_problem(packs.dgrad(r["block"].conv2), [t], o) for r, t, o in zip(recs, dh2, dh1a)])
     dh1 = [plan.buf(v.B, v.H, v.W, v.C) for v in dh1a]
+    wg = []
     for r, a, t, do in zip(recs, dh1a, dh1, d_outs):
         b = r["block"]
         plan.call(lambda r=r, a=a, t=t: ops.leaky_bwd(r["h1a"], a, t), "leaky bwd")
-        plan.call(lambda r=r, t=t, b=b: ops.conv_wgrad(r["x"], t, g(b.conv1.weight), g(b.conv1.bias)), "wgrad conv1")
+        wg += ops.wgrad_problems(r["x"], t, g(b.conv1.weight), g(b.conv1.bias))
         if b.skip is not None:
-            plan.call(lambda r=r, do=do, b=b: ops.conv_wgrad(r["x"], do, g(b.skip.weight), g(b.skip.bias)), "wgrad skip")
+            wg += ops.wgrad_problems(r["x"], do, g(b.skip.weight), g(b.skip.bias))
+    plan.wgrad(wg)
     if not need_dx:
         return None
     cin = [sum(v.C for v in r["x"]) for r in recs]

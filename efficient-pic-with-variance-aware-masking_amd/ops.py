@@ -351,18 +351,33 @@ def pack_conv_dgrad(weight: torch.Tensor) -> Packed:
     return Packed(w, None, kh, kw, n_out, c_in, 1, kh // 2, kw // 2)
 
 
-def conv_wgrad(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]):
-    """dw (OIHW) / db of a stride-1 conv whose input was the channel concat of ``x_segs``."""
-    lib = L.load()
+def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]) -> List[L.VamWgrad]:
+    """dw (OIHW) / db of a stride-1 conv whose input was the channel concat of ``x_segs``: one problem per segment."""
     n, cin_total, kh, kw = dw.shape
-    assert dy.C == n and sum(v.C for v in x_segs) == cin_total and dw.is_contiguous()
-    off = 0
+    assert dy.C == n and sum(v.C for v in x_segs) == cin_total and dw.is_contiguous() and kh == kw
+    out, off = [], 0
     for v in x_segs:
-        L.check(lib.vam_conv_wgrad(v.ptr, v.ld, dy.ptr, dy.ld, v.B, v.H, v.W, kh, kw, v.C, n, dw.data_ptr(), cin_total, off,
-                                   stream_ptr()), "vam_conv_wgrad")
+        assert (v.B, v.H, v.W) == (dy.B, dy.H, dy.W)
+        p = L.VamWgrad()
+        p.x, p.dy, p.dw = v.ptr, dy.ptr, dw.data_ptr()
+        p.db = db.data_ptr() if (db is not None and off == 0) else None
+        p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, v.B, v.H, v.W, kh, kw, v.C, n
+        p.cin_total, p.c_off = cin_total, off
+        out.append(p)
         off += v.C
-    if db is not None:
-        L.check(lib.vam_colsum(dy.ptr, dy.ld, dy.n_pix, n, db.data_ptr(), stream_ptr()), "vam_colsum")
+    return out
+
+
+def wgrad_group(problems: Sequence[L.VamWgrad]):
+    lib = L.load()
+    for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
+        chunk = list(problems[i:i + L.VAM_MAX_WGRAD_GROUP])
+        arr = (L.VamWgrad * len(chunk))(*chunk)
+        L.check(lib.vam_conv_wgrad_group(arr, len(chunk), stream_ptr()), "vam_conv_wgrad_group")
+
+
+def conv_wgrad(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]):
+    wgrad_group(wgrad_problems(x_segs, dy, dw, db))
 
 
 def leaky_bwd(act: View, dy: View, dx: View):

@@ -40,3 +40,23 @@ def whole_job_megapixels_per_s(images_per_rank: int, height: int, width: int, st
                                max_seconds: float) -> float:
     """value = pixels processed by ALL ranks / slowest rank's time (weak scaling)."""
     return world * images_per_rank * height * width * steps / 1e6 / max_seconds
+
+
+def all_reduce_gradients(params) -> int:
+    """Average the gradients of ``params`` over the ranks with ONE collective on a flat bucket (the fine-tune
+    step's only exchange: BASELINE north_star "RCCL all-reduce over xGMI on the gradients only").  Returns the
+    number of bytes reduced (0 when not distributed)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return flat.numel() * flat.element_size()

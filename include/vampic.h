@@ -211,11 +211,26 @@ int vam_memset_zero(void* ptr, size_t bytes, void* stream);
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
 
 /* ------------------------------------------------------------------ REM fine-tune backward (configs[4]) */
-/* Weight gradient of a stride-1, pad k/2 convolution (autograd's conv backward-weight for layers/rem.py:40-49):
- * dw[n][c_off + c][ty][tx] = sum_p dy[p][n] * x[pix(p)+(ty-k/2, tx-k/2)][c], OIHW with `cin_total` input
- * channels; x is a C-channel window (one segment of a concatenated input lands at c_off). Fixed summation order. */
+/* Weight (and bias) gradient of a stride-1, pad k/2 convolution (autograd's conv backward-weight for
+ * layers/rem.py:40-49):  dw[n][c_off + c][ty][tx] = sum_p dy[p][n] * x[pix(p)+(ty-k/2, tx-k/2)][c]  in OIHW with
+ * `cin_total` input channels; x is a C-channel window (one segment of a concatenated input lands at c_off).
+ * db (may be NULL; honoured by the problem with c_off == 0) = sum_p dy[p][n].  Fixed summation order.
+ * Up to VAM_MAX_WGRAD_GROUP independent problems run in one launch (the ten slices' REM blocks in lockstep). */
+#define VAM_MAX_WGRAD_GROUP 16
+typedef struct vam_wgrad {
+  const float* x;
+  const float* dy;
+  float* dw;
+  float* db;
+  int ld_x, ld_dy;
+  int B, H, W;
+  int kh, kw;
+  int C, N;
+  int cin_total, c_off;
+} vam_wgrad;
+int vam_conv_wgrad_group(const vam_wgrad* problems, int n_problems, void* stream);
 int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw,
-                   int C, int N, float* dw_oihw, int cin_total, int c_off, void* stream);
+                   int C, int N, float* dw_oihw, float* db, int cin_total, int c_off, void* stream);
 /* out[n] = sum_p dy[p][n]  (bias gradient) */
 int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream);
 /* dx = dy * (act > 0 ? 1 : 0.01): LeakyReLU(0.01) backward from its OUTPUT (same sign as its input) */

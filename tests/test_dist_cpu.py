@@ -56,3 +56,53 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((3, 4), float(rank + 1))
+    ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    nbytes = sharding.all_reduce_gradients(ps)                   # ps[2] has no gradient: skipped
+    q.put((rank, nbytes, ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_two_ranks():
+    """The fine-tune step's only collective: one flat bucket, mean over ranks (REM gradients)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, nbytes, g0, g1, g2 in res:
+        assert nbytes == 17 * 4
+        assert torch.equal(g0, torch.full((3, 4), 1.5))
+        assert torch.equal(g1, torch.arange(5, dtype=torch.float32) * 1.5)
+        assert g2 is None
+
+
+def test_finetune_host_logic():
+    """extract_quality_ref / rems_quality_list / RateLoss mirror training/step.py:14-32, train.py:167-181,
+    training/loss.py:189-229."""
+    import math
+    from vampic import finetune as ft
+    assert ft.extract_quality_ref(0.5, [0.75]) is None
+    assert ft.extract_quality_ref(2.5, [0.75]) == 0.75
+    assert ft.extract_quality_ref(1.0, [0.75, 2.0]) == 0.75 and ft.extract_quality_ref(5.0, [0.75, 2.0]) == 2.0
+    assert ft.extract_quality_ref(2.0, [0.5, 1.0, 3.0]) == 1.0 and ft.extract_quality_ref(7.0, [0.5, 1.0, 3.0]) == 3.0
+    qs = ft.rems_quality_list([0.75], [10])
+    assert qs[0] == 0.76 and qs[-1] == 10 and all(q > 0.75 for q in qs) and len(qs) == 11
+    x = torch.rand(2, 3, 8, 8)
+    out = {"x_hat": x.clone(), "likelihoods": {"y": torch.full((2, 4, 2, 2), 0.5), "z": torch.full((2, 2, 1, 1), 0.25)}}
+    c = ft.RateLoss()(out, x)
+    n_pix = 2 * 8 * 8
+    assert abs(float(c["bpp_base"]) - 32 * 1.0 / n_pix) < 1e-6 and abs(float(c["bpp_hype"]) - 4 * 2.0 / n_pix) < 1e-6
+    assert abs(float(c["loss"]) - (32 + 2 * 8) / n_pix) < 1e-6 and float(c["mse_loss"].mean()) == 0.0
