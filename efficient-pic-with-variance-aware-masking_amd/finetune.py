@@ -74,13 +74,18 @@ def rems_quality_list(check_levels: Sequence[float], check_levels_np: Sequence[i
 
 
 def finetune_step(model, criterion, batch: torch.Tensor, optimizer, quality: float, check_levels: Sequence[float],
-                  clip_max_norm: float = 1.0, noise=None) -> dict:
-    """One optimisation step on this rank's shard of the batch (training/step.py:56-95)."""
+                  clip_max_norm: float = 1.0, noise=None, fused: bool = True) -> dict:
+    """One optimisation step on this rank's shard of the batch (training/step.py:56-95).  ``fused``: the
+    checkpoint latent comes out of the training forward's own front end (``forward_finetune``, same bits) instead
+    of a separate ``ExtractChekpointRepr`` pass."""
     optimizer.zero_grad()
-    q_ref = extract_quality_ref(quality, check_levels)
-    with torch.no_grad():
-        ck = None if q_ref is None else model.ExtractChekpointRepr(batch, quality=q_ref, rc=False)
-    out = model.forward_single_quality(batch, quality=quality, training=True, checkpoint_ref=ck, noise=noise)
+    if fused:
+        out = model.forward_finetune(batch, quality, noise=noise)
+    else:
+        q_ref = extract_quality_ref(quality, check_levels)
+        with torch.no_grad():
+            ck = None if q_ref is None else model.ExtractChekpointRepr(batch, quality=q_ref, rc=False)
+        out = model.forward_single_quality(batch, quality=quality, training=True, checkpoint_ref=ck, noise=noise)
     crit = criterion(out, batch)
     crit["loss"].backward()
     sharding.all_reduce_gradients(p for p in model.parameters() if p.requires_grad)

@@ -249,16 +249,17 @@ class VarianceMaskingPIC(CompressionModel):
                                       "dim_chunk 32, division [d, 2d], 5 support slices)")
 
     def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False,
-              train: bool = False) -> "_FsqPlan":
+              train: bool = False, own_ck: bool = False) -> "_FsqPlan":
         B, C_, H, W = x.shape
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
-        key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ())
+        key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ()) + \
+            (("own_ck",) if own_ck else ())
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
         if p is None:
-            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train)
+            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck)
             self._plans[key] = p
         return p
 
@@ -462,7 +463,19 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
         return plan.execute(x, pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, clone)
 
-    def _forward_train(self, x, mask_pol, quality, checkpoint_ref, noise):
+    def forward_finetune(self, x, quality, mask_pol="point-based-std", noise=None):
+        """One fused plan for the fine-tune step's two forward passes: bit-identical to
+        ``ck = ExtractChekpointRepr(x, q_ref, rc=False); forward_single_quality(x, quality, training=True,
+        checkpoint_ref=ck)`` (training/step.py:67-76) because everything up to the progressive (mu, sigma) chain
+        does not depend on the quality — the checkpoint latent is derived from the same front end instead of a
+        second run of g_a / hyperprior / slices."""
+        from .finetune import extract_quality_ref
+        q_ref = extract_quality_ref(quality, self.check_levels)
+        if q_ref is None:
+            return self._forward_train(x, mask_pol, quality, None, noise)
+        return self._forward_train(x, mask_pol, quality, "own", noise, ck_pr=q_ref)
+
+    def _forward_train(self, x, mask_pol, quality, checkpoint_ref, noise, ck_pr=None):
         """Training-mode forward (rem_pic.py:229-422 with training=True; training/step.py:62-76).  Everything
         outside ``post_latent`` must be frozen (``freeze_all(); unfreeze_rems()``): those transforms have no
         backward kernels in this build, and silently dropping their gradients would be wrong."""
@@ -478,12 +491,17 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         self._check_config()
         if not self.mu_std:
             raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
-        if checkpoint_ref is not None:
+        own = isinstance(checkpoint_ref, str)
+        if checkpoint_ref is not None and not own:
             checkpoint_ref = checkpoint_ref.detach()
         rem_idx = self._rem_choice(quality, checkpoint_ref) if quality != 0 else None
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
-        plan = self._plan(x.detach(), base_only=(quality == 0), rem_idx=rem_idx, train=True)
-        out = plan.execute(x.detach(), pr, checkpoint_ref if rem_idx is not None else None, self.use_graph, True, noise=noise)
+        own = own and rem_idx is not None
+        if own and mask_pol == "two-levels":
+            ck_pr = 10 if ck_pr != 0 else 0
+        plan = self._plan(x.detach(), base_only=(quality == 0), rem_idx=rem_idx, train=True, own_ck=own)
+        out = plan.execute(x.detach(), pr, checkpoint_ref if (rem_idx is not None and not own) else None, self.use_graph,
+                           True, noise=noise, ck_pr=ck_pr if own else None)
         if rem_idx is not None and torch.is_grad_enabled() and any(p.requires_grad for p in plan.rem_params):
             out["likelihoods"]["y"] = _RemTrainFn.apply(plan, out["likelihoods"]["y"], self.use_graph, *plan.rem_params)
         return out
@@ -544,8 +562,10 @@ class _RemTrainFn(torch.autograd.Function):
 class _FsqPlan:
     """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
 
-    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False, train=False):
+    def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False, train=False,
+                 own_ck=False):
         self.m, self.B, self.H, self.W = m, B, H, W
+        self.own_ck, self.ck_pr = own_ck, 0.0     # fine-tune: derive the checkpoint latent inside this plan
         self.base_only, self.rem_idx = base_only, rem_idx
         self.symbols = symbols
         self.train = train          # additive-noise likelihoods (+ taped REM and a backward plan when rem_idx is set)
@@ -637,7 +657,8 @@ class _FsqPlan:
                     base_done[i] = ev
 
         if base_only:
-            E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
+            if not symbols:                              # compress() does not decode (pic.py:671-860)
+                E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
             return
 
         # ---- progressive slices                                                    pic.py:577-643
@@ -667,6 +688,16 @@ class _FsqPlan:
         mu_f, std_f = self.mu_p, self.std_p
         if rem_idx is not None:                                                       # rem_pic.py:363-377
             self.ck = plan.buf(B, h, w, d)
+            if own_ck:
+                # y_hat at the check level from the SAME front end (everything up to here is quality independent;
+                # at q <= check_levels[0] no REM applies): what ExtractChekpointRepr(x, q_ref) returns, pic.py:621-641
+                m_ck, rq_ck, junk = plan.buf(B, h, w, d), plan.buf(B, h, w, d), plan.buf(B, h, w, d)
+                plan.call(lambda: ops.variance_mask(self.std_p, self.ck_pr, m_ck, n_slice=ns))
+                plan.call(lambda: ops.gauss_tail(y.window(d, d), self.mu_p, self.std_p, y2=y.window(0, d), mask=m_ck,
+                                                 yhat=rq_ck, lik=junk))
+                E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)],
+                               [msups[j] + [sl(rq_ck, j)] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
+                               [dict(act=L.ACT_HALF_TANH, post=sl(rq_ck, j), post2=sl(yb, j)) for j in range(ns)])
             att = plan.buf(B, h, w, d)
             plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
             mu_f, std_f = plan.buf(B, h, w, d), plan.buf(B, h, w, d)
@@ -718,7 +749,8 @@ class _FsqPlan:
         E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
                        [sl(yp, j) for j in range(ns)],
                        [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)])   # :635-641
-        E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
+        if not symbols:
+            E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
 
     # -------------------------------------------------------------------------------------------
     def set_noise(self, noise=None):
@@ -754,10 +786,11 @@ class _FsqPlan:
             off += p.numel()
         return out
 
-    def execute(self, x, pr, checkpoint_ref, use_graph, clone, noise=None):
+    def execute(self, x, pr, checkpoint_ref, use_graph, clone, noise=None, ck_pr=None):
         """Run the plan on the model's own HIP stream (hipGraph capture is not allowed on the
         legacy default stream), ordered after / before the caller's current stream."""
         self.pr = float(pr)
+        self.ck_pr = float(ck_pr) if ck_pr is not None else 0.0
         if self.train and self.rem_idx is not None:
             sig = tuple(p.data_ptr() for p in self.rem_params)
             if getattr(self, "_ptr_sig", sig) != sig:          # parameter storage replaced: captured pointers are stale
@@ -776,7 +809,7 @@ class _FsqPlan:
                 ck = ops.from_nchw(checkpoint_ref.to(self.x_in.device))
                 self.ck.buf.copy_(ck.buf[..., ck.c0:ck.c0 + ck.C])
             if use_graph:
-                g = self.graphs.get(self.pr)
+                g = self.graphs.get((self.pr, self.ck_pr))
                 if g is None:
                     self.plan.run()                      # warm-up: every code object loaded before capture
                     self.stream.synchronize()
@@ -784,7 +817,7 @@ class _FsqPlan:
                     g.capture(self.plan.run)
                     if len(self.graphs) > 32:
                         self.graphs.clear()
-                    self.graphs[self.pr] = g
+                    self.graphs[(self.pr, self.ck_pr)] = g
                 g.launch()
             else:
                 self.plan.run()

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=float, default=2.5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--two-pass", action="store_true", help="separate ExtractChekpointRepr pass, as the reference loop")
     a = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     dist = None
@@ -73,11 +74,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(max(a.warmup, 1)):
-        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75])
+        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75])
+        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
     sync()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
 
@@ -91,7 +92,11 @@ def main():
     with torch.no_grad():
         ck, t_ck = timed(lambda: net.ExtractChekpointRepr(x, quality=0.75, rc=False))
     opt.zero_grad()
-    out, t_fwd = timed(lambda: net.forward_single_quality(x, quality=a.quality, training=True, checkpoint_ref=ck))
+    if a.two_pass:
+        out, t_fwd = timed(lambda: net.forward_single_quality(x, quality=a.quality, training=True, checkpoint_ref=ck))
+    else:
+        t_ck = 0.0
+        out, t_fwd = timed(lambda: net.forward_finetune(x, a.quality))
     loss = crit(out, x)["loss"]
     _, t_bwd = timed(loss.backward)
     _, t_ar = timed(lambda: sharding.all_reduce_gradients(p for p in net.parameters() if p.requires_grad))
@@ -105,7 +110,7 @@ def main():
                           "data": "synthetic",
                           "config": {"workload": f"REM fine-tune step q={a.quality}, check level 0.75, {a.batch}x3x{a.size}x{a.size} per GPU",
                                      "global_batch": a.batch * world, "trainable_params": n_par,
-                                     "grad_bucket_bytes": 4 * n_par, "hip_graph": not a.no_graph,
+                                     "grad_bucket_bytes": 4 * n_par, "hip_graph": not a.no_graph, "fused_checkpoint": not a.two_pass,
                                      "loss": round(float(c["loss"].detach()), 5)},
                           "phase_ms": {"checkpoint_forward": round(t_ck, 3), "train_forward": round(t_fwd, 3),
                                        "backward": round(t_bwd, 3), "grad_all_reduce": round(t_ar, 3),

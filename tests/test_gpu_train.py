@@ -232,6 +232,30 @@ def test_rem_finetune_loop_reduces_rate(train_model):
     assert out["likelihoods"]["y"].requires_grad and torch.isfinite(out["likelihoods"]["y"]).all()
 
 
+def test_fused_finetune_forward_equals_two_pass(train_model):
+    """forward_finetune (checkpoint latent derived inside the training plan) against the reference's two calls
+    (ExtractChekpointRepr, then forward_single_quality(training=True, checkpoint_ref=...)): same bits out, same
+    gradients."""
+    m0, _ = train_model
+    m = copy.deepcopy(m0)
+    x = synth.synth_image(2, 64, 128, seed=5).cuda()
+    noise = {"y": (synth.uniform((2, 640, 4, 8), 17) - 0.5).cuda(), "z": (synth.uniform((2, 192, 1, 2), 18) - 0.5).cuda()}
+    res = []
+    for fused in (False, True):
+        m.zero_grad(set_to_none=True)
+        if fused:
+            out = m.forward_finetune(x, 3.0, noise=noise)
+        else:
+            with torch.no_grad():
+                ck = m.ExtractChekpointRepr(x, quality=0.75, rc=False)
+            out = m.forward_single_quality(x, quality=3.0, training=True, checkpoint_ref=ck, noise=noise)
+        _rate_loss(out, x).backward()
+        res.append((out["likelihoods"]["y"].detach().clone(), out["x_hat"].clone(),
+                    torch.cat([p.grad.reshape(-1) for p in m.post_latent.parameters()])))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_training_outside_rem_fails_loudly(train_model):
     m0, _ = train_model
     m = copy.deepcopy(m0)
