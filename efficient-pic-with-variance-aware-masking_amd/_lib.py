@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvampic.so")
+LIB_PATH = os.environ.get("VAMPIC_LIB", os.path.join(_HERE, "libvampic.so"))      # override: A/B kernel experiments
 
 VAM_MAX_SEG = 4
 VAM_MAX_GROUP = 8

@@ -98,3 +98,53 @@ def compress_with_ac(model, images: Iterable[torch.Tensor], pr_list: Sequence[fl
                 t_dec[j].append(t2 - t1)
     avg = lambda rows: [sum(v) / len(v) for v in rows]
     return avg(bpp), avg(psnr), avg(t_enc), avg(t_dec)
+
+
+def valid_epoch(epoch: int, test_dataloader: Iterable[torch.Tensor], criterion, model, pr_list: Sequence[float] = (0.05,),
+                rems: Optional[Sequence[float]] = None):
+    """training/step.py:136-202 (without wandb): mean criterion loss over batches x qualities — what drives the
+    ReduceLROnPlateau scheduler of train.py:130,279.  ``rems`` = the check levels (REM models) or None."""
+    from .finetune import extract_quality_ref
+    model.eval()
+    device = next(model.parameters()).device
+    tot = {"loss": 0.0, "bpp": 0.0, "mse": 0.0, "psnr": 0.0}
+    n = 0
+    with torch.no_grad():
+        for d in test_dataloader:
+            d = d.to(device)
+            for p in pr_list:
+                if rems is None:
+                    out = model.forward_single_quality(d, quality=p, training=False)
+                else:
+                    q_ref = extract_quality_ref(p, rems)
+                    ck = None if q_ref is None else model.ExtractChekpointRepr(d, quality=q_ref, rc=False)
+                    out = model.forward_single_quality(d, quality=p, training=False, checkpoint_ref=ck)
+                crit = criterion(out, d)
+                psnr = compute_psnr(d, out["x_hat"])
+                tot["loss"] += float(crit["loss"])
+                tot["bpp"] += float(crit["bpp_loss"])
+                tot["mse"] += 10.0 ** (-psnr / 10.0)
+                tot["psnr"] += psnr
+                n += 1
+    n = max(n, 1)
+    return tot["loss"] / n, {k: v / n for k, v in tot.items()}
+
+
+def read_image(filepath) -> torch.Tensor:
+    """utility/functions.py:62-66: RGB image file -> float32 [3,H,W] in [0,1] (what torchvision's ToTensor does to
+    an 8-bit image: value / 255, HWC -> CHW)."""
+    import numpy as np
+    from PIL import Image
+    img = Image.open(filepath).convert("RGB")
+    a = np.asarray(img, dtype=np.uint8)
+    return torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div(255.0)
+
+
+def write_image(x: torch.Tensor, filepath):
+    """Inverse of :func:`read_image` for a [3,H,W] or [1,3,H,W] tensor in [0,1] (demo.py saves reconstructions)."""
+    import numpy as np
+    from PIL import Image
+    if x.dim() == 4:
+        x = x[0]
+    a = (x.detach().clamp(0, 1).mul(255.0).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy())
+    Image.fromarray(np.ascontiguousarray(a), mode="RGB").save(filepath)

@@ -187,6 +187,39 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "rem_train_step.npz"), **rec)
     net.eval()
 
+    # 7. host utilities (utility/functions.py, imported with the torchvision / pytorch_msssim / wandb stand-ins):
+    #    key remapping of initialize_model_from_pretrained / replace_keys, compute_padding, compute_psnr
+    spec = importlib.util.spec_from_file_location("ref_utility_functions", os.path.join(REF, "utility", "functions.py"))
+    UF = importlib.util.module_from_spec(spec)         # utility/__init__.py pulls seaborn (absent): load the file alone
+    spec.loader.exec_module(UF)
+    single = ["g_a.0.weight", "g_a.1.beta", "g_a.1.gamma", "g_s.0.weight", "g_s.8.bias", "h_a.0.weight", "h_a.8.bias",
+              "h_mean_s.0.weight", "h_mean_s.8.bias", "h_scale_s.0.weight", "h_scale_s.6.0.bias",
+              "cc_mean_transforms.0.0.weight", "lrp_transforms.3.8.bias", "gaussian_conditional.scale_table",
+              "entropy_bottleneck._matrix0", "entropy_bottleneck.quantiles", "something_else.weight"]
+    ck = {k: torch.full((1,), float(i)) for i, k in enumerate(single)}
+    enh = {k: torch.full((1,), 100.0 + i) for i, k in enumerate(["g_s.0.weight", "g_s.8.bias", "g_a.0.weight"])}
+    util = {"init": {}, "replace": {}, "padding": {}, "psnr": {}}
+    for md in (False, True):
+        for me in (False, True):
+            for mh in (False, True):
+                for with_enh in (False, True):
+                    a_ = argparse.Namespace(multiple_decoder=md, multiple_encoder=me, multiple_hyperprior=mh)
+                    r = quiet(UF.initialize_model_from_pretrained, ck, a_, enh if with_enh else None)
+                    util["init"][f"{int(md)}{int(me)}{int(mh)}{int(with_enh)}"] = [[k, float(v)] for k, v in r.items()]
+    old = {k: torch.full((1,), float(i)) for i, k in enumerate(["g_a.0.weight", "g_a_enh.0.weight", "g_a.1.beta", "g_s.0.weight"])}
+    new = {k: torch.full((1,), float(i)) for i, k in enumerate(["g_a.0.0.weight", "g_a.0.1.beta", "g_a.1.0.weight"])}
+    for me in (False, True):
+        util["replace"][f"old{int(me)}"] = [[k, float(v)] for k, v in UF.replace_keys(old, me).items()]
+        util["replace"][f"new{int(me)}"] = [[k, float(v)] for k, v in UF.replace_keys(new, me).items()]
+    for (hh, ww) in ((512, 768), (500, 333), (1, 1), (64, 65), (1200, 1999)):
+        util["padding"][f"{hh}x{ww}"] = [list(t) for t in UF.compute_padding(hh, ww, min_div=64)]
+    for seed in (1, 2):
+        a_, b_ = synth.uniform((2, 3, 16, 24), seed), synth.uniform((2, 3, 16, 24), seed + 10)
+        util["psnr"][str(seed)] = UF.compute_psnr(a_, b_)
+    util["savepath"] = list(UF.create_savepath("/x/y"))
+    with open(os.path.join(GOLD, "host_utils.json"), "w") as f:
+        json.dump(util, f)
+
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):
         print(f"  {fn}: {os.path.getsize(os.path.join(GOLD, fn)) / 1024:.1f} KiB")

@@ -227,6 +227,17 @@ def test_rem_finetune_loop_reduces_rate(train_model):
     for n, p in m.named_parameters():
         if not n.startswith("post_latent."):
             assert torch.equal(p, frozen[n]), n
+    # validation driver (training/step.py:136-202) on the fine-tuned model: same numbers as the manual eval pass
+    from vampic.evaluate import valid_epoch
+    from vampic.finetune import RateLoss
+    m.eval()
+    v_loss, v = valid_epoch(0, [x], RateLoss(), m, pr_list=[2.5], rems=[0.75])
+    den = -math.log(2) * x.shape[0] * x.shape[2] * x.shape[3]
+    with torch.no_grad():
+        o = m.forward_single_quality(x, quality=2.5, training=False, checkpoint_ref=ck)
+    want = float(torch.log(o["likelihoods"]["y"]).sum() / den + 2 * torch.log(o["likelihoods"]["z"]).sum() / den)
+    assert abs(v_loss - want) <= 1e-5 * abs(want) and v["psnr"] > 0
+    m.train()
     # random noise path (the reference's uniform_): finite, differentiable
     out = m.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck)
     assert out["likelihoods"]["y"].requires_grad and torch.isfinite(out["likelihoods"]["y"]).all()

@@ -82,3 +82,73 @@ def test_rem_bookkeeping(synth_model_cpu):
             if q > cl[0]:
                 net2 = type("T", (), {"check_levels": cl, "num_rems": len(cl)})()
                 assert vampic.VarianceMaskingPICREM._rem_index(net2, q) == O.rem_index(cl, q)
+
+
+def test_checkpoint_helpers_match_reference():
+    """Key remapping / padding / PSNR / paths against what the reference's utility/functions.py returned
+    (tests/golden/host_utils.json, oracle/gen_golden.py §7), plus a save/load round trip."""
+    import argparse
+    import json
+    import math
+    import tempfile
+    import torch
+    import vampic.synth as synth
+    from vampic import checkpoint as ck
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_utils.json")))
+    single = ["g_a.0.weight", "g_a.1.beta", "g_a.1.gamma", "g_s.0.weight", "g_s.8.bias", "h_a.0.weight", "h_a.8.bias",
+              "h_mean_s.0.weight", "h_mean_s.8.bias", "h_scale_s.0.weight", "h_scale_s.6.0.bias",
+              "cc_mean_transforms.0.0.weight", "lrp_transforms.3.8.bias", "gaussian_conditional.scale_table",
+              "entropy_bottleneck._matrix0", "entropy_bottleneck.quantiles", "something_else.weight"]
+    base = {k: torch.full((1,), float(i)) for i, k in enumerate(single)}
+    enh = {k: torch.full((1,), 100.0 + i) for i, k in enumerate(["g_s.0.weight", "g_s.8.bias", "g_a.0.weight"])}
+    for tag, want in gold["init"].items():
+        md, me, mh, we = (c == "1" for c in tag)
+        a = argparse.Namespace(multiple_decoder=md, multiple_encoder=me, multiple_hyperprior=mh)
+        got = ck.initialize_model_from_pretrained(base, a, enh if we else None)
+        assert [[k, float(v)] for k, v in got.items()] == want, tag          # same keys, same order, same tensors
+    old = {k: torch.full((1,), float(i)) for i, k in enumerate(["g_a.0.weight", "g_a_enh.0.weight", "g_a.1.beta", "g_s.0.weight"])}
+    new = {k: torch.full((1,), float(i)) for i, k in enumerate(["g_a.0.0.weight", "g_a.0.1.beta", "g_a.1.0.weight"])}
+    for me in (False, True):
+        assert [[k, float(v)] for k, v in ck.replace_keys(old, me).items()] == gold["replace"][f"old{int(me)}"]
+        assert [[k, float(v)] for k, v in ck.replace_keys(new, me).items()] == gold["replace"][f"new{int(me)}"]
+    from vampic.evaluate import compute_padding
+    for key, want in gold["padding"].items():
+        hh, ww = (int(v) for v in key.split("x"))
+        assert [list(t) for t in compute_padding(hh, ww, min_div=64)] == want
+    for seed, want in gold["psnr"].items():
+        a_, b_ = synth.uniform((2, 3, 16, 24), int(seed)), synth.uniform((2, 3, 16, 24), int(seed) + 10)
+        assert abs(-10 * math.log10(torch.mean((a_ - b_) ** 2).item()) - want) < 1e-9   # host formula; GPU path in test_gpu_bitstream
+    assert list(ck.create_savepath("/x/y")) == gold["savepath"]
+    m = ck.AverageMeter()
+    m.update(2.0)
+    m.update(4.0, n=3)
+    assert m.avg == 3.5 and m.count == 4
+    with tempfile.TemporaryDirectory() as d:
+        last, best = ck.create_savepath(d)
+        lin = torch.nn.Linear(3, 2)
+        ck.save_checkpoint({"epoch": 3, "state_dict": lin.state_dict()}, False, last, best)
+        ck.save_checkpoint({"epoch": 4, "state_dict": lin.state_dict()}, True, last, best)
+        lin2 = torch.nn.Linear(3, 2)
+        assert ck.load_checkpoint(best, lin2)["epoch"] == 4 and ck.load_checkpoint(last)["epoch"] == 3
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(lin.state_dict().values(), lin2.state_dict().values()))
+    args = argparse.Namespace(learning_rate=1e-4, aux_learning_rate=1e-3, training_type="rems")
+    net = torch.nn.Module()
+    net.a = torch.nn.Linear(2, 2)
+    net.eb = torch.nn.Module()
+    net.eb.quantiles = torch.nn.Parameter(torch.zeros(1))
+    opt, aux = ck.configure_optimizers(net, args)
+    assert aux is None and len(opt.param_groups[0]["params"]) == 2          # eb.quantiles is not in the main optimiser
+    args.training_type = "first_strain"
+    opt, aux = ck.configure_optimizers(net, args)
+    assert aux is not None and len(aux.param_groups[0]["params"]) == 1
+
+
+def test_image_io_round_trip(tmp_path):
+    import torch
+    import vampic.synth as synth
+    from vampic.evaluate import read_image, write_image
+    x = (synth.uniform((3, 20, 31), 3) * 255).round() / 255
+    p = tmp_path / "a.png"
+    write_image(x, p)
+    y = read_image(p)
+    assert y.dtype == torch.float32 and y.shape == (3, 20, 31) and torch.equal(y, x)
