@@ -76,10 +76,15 @@ constexpr int PK = 16;  // packing granularity of the weight buffer along K
 template <int BM, int BN, int BK, int WGM, int WGN>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const GroupArgs args) {
   constexpr int NT = WGM * WGN * 64;         // threads per block
-  constexpr int LDS_LD = BK + 4;             // floats per LDS row
+  constexpr int LDS_LD = BK;                 // floats per LDS row: no padding, the 16-byte chunks of a row are
+                                             // XOR-swizzled instead (below) so that both the staging writes and
+                                             // the MFMA operand reads are bank-conflict free
   constexpr int TM = BM / WGM / 32;          // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
   constexpr int CPR = BK / 4;                // float4 chunks per row
+  // chunk c of row r lives at chunk c ^ ((r >> SW_SHIFT) & (CPR-1)): 16 consecutive lanes of a ds_write_b128
+  // (16/CPR whole rows) and of a ds_read_b128 (16 rows, one logical chunk) each cover all 64 banks once
+  constexpr int SW_SHIFT = (CPR == 4) ? 2 : 1;
   constexpr int RPP = NT / CPR;              // rows covered per pass of the block
   constexpr int NA = (BM + RPP - 1) / RPP;   // A float4 per thread
   constexpr int NB = (BN + RPP - 1) / RPP;
@@ -116,6 +121,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   }
   if (pi < 0) return;
   const ConvP& P = args.p[pi];
+  // Block-uniform problem fields used by the main loop, pinned to SGPRs.  Without this hipcc re-loads some of
+  // them inside the (lane-divergent) row-decode branch below, the value comes out of that branch in a VGPR, and
+  // everything derived from it — tap count, chunk count, the chunk state, the loop condition — turns into
+  // vector code with an exec-masked loop (seen in the ISA: v_cmp loop exit, v_cndmask chunk state).
+  const int u_kh = __builtin_amdgcn_readfirstlane(P.kh), u_kw = __builtin_amdgcn_readfirstlane(P.kw);
+  const int u_W = __builtin_amdgcn_readfirstlane(P.W), u_Kc = __builtin_amdgcn_readfirstlane(P.Kc);
+  const int u_kc16 = __builtin_amdgcn_readfirstlane(P.Kc16), u_Npad = __builtin_amdgcn_readfirstlane(P.Npad);
+  const int u_se0 = __builtin_amdgcn_readfirstlane(P.seg_end[0]), u_se1 = __builtin_amdgcn_readfirstlane(P.seg_end[1]);
+  const int u_se2 = __builtin_amdgcn_readfirstlane(P.seg_end[2]);
   const int tn = t % P.tiles_n, tm = t / P.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -142,9 +156,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       const int iy0 = oy * P.stride - P.pad_y, ix0 = ox * P.stride - P.pad_x;
       a_pix0[i] = b * P.HW + iy0 * P.W + ix0;
       unsigned m = 0u;
-      for (int ty = 0; ty < P.kh; ++ty)
-        for (int tx = 0; tx < P.kw; ++tx)
-          if ((unsigned)(iy0 + ty) < (unsigned)P.H && (unsigned)(ix0 + tx) < (unsigned)P.W) m |= 1u << (ty * P.kw + tx);
+      for (int ty = 0; ty < u_kh; ++ty)
+        for (int tx = 0; tx < u_kw; ++tx)
+          if ((unsigned)(iy0 + ty) < (unsigned)P.H && (unsigned)(ix0 + tx) < (unsigned)P.W) m |= 1u << (ty * u_kw + tx);
       a_mask[i] = m;
     }
   }
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   for (int i = 0; i < NB; ++i) {
     const int r = ld_row + i * RPP;
     const bool ok = (B_FULL || r < BN) && (n0 + r < P.Npad);
-    b_off[i] = ok ? (unsigned)((((ld_col >> 4) * P.Npad + n0 + r) * PK + (ld_col & 15)) * 4) : 0x80000000u;
+    b_off[i] = ok ? (unsigned)((((ld_col >> 4) * u_Npad + n0 + r) * PK + (ld_col & 15)) * 4) : 0x80000000u;
   }
   const unsigned long long wpa = reinterpret_cast<unsigned long long>(P.wpack);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -166,9 +180,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   // written to LDS one iteration later, so a load has two compute phases to land (L2-miss
   // latency is ~2 us under load; one K chunk of MFMAs is 0.2-1.3 us).
   float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  const int n_taps = P.kh * P.kw;
-  const int n_chunks = n_taps * P.Kc;        // Kc = K chunks of BK per tap
-  const int kc16 = P.Kc16;                   // 16-channel packing chunks per tap
+  const int n_taps = u_kh * u_kw;
+  const int n_chunks = n_taps * u_Kc;        // Kc = K chunks of BK per tap
+  const int kc16 = u_kc16;                   // 16-channel packing chunks per tap
 
   // chunk state (block-uniform)
   int c_ty = 0, c_tx = 0, c_kc = 0, c_tap = 0;
@@ -179,9 +193,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
     const int cc0 = c_kc * BK;
     // segment holding channel cc0 (unused segments end at 2^30); branch-free and explicitly uniform
-    const int c_seg = __builtin_amdgcn_readfirstlane((cc0 >= P.seg_end[0] ? 1 : 0) + (cc0 >= P.seg_end[1] ? 1 : 0) +
-                                                     (cc0 >= P.seg_end[2] ? 1 : 0));
-    const int seg_begin = c_seg ? P.seg_end[c_seg - 1] : 0;
+    const int c_seg = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
+    const int seg_begin = c_seg == 0 ? 0 : (c_seg == 1 ? u_se0 : (c_seg == 2 ? u_se1 : u_se2));
     // readfirstlane makes the descriptor PROVABLY wave-uniform; without it hipcc wraps every
     // buffer load in a waterfall loop with a vmcnt(0) in between (cdna guide T20).
     const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[c_seg]);
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((unsigned long long)sp_hi << 32) | sp_lo), 0, 0x7FFFFFFF, 0x00020000);
     const int sld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[c_seg]) * 4;
-    const int tap_pix = c_ty * P.W + c_tx;                         // uniform
+    const int tap_pix = c_ty * u_W + c_tx;                         // uniform
     const int col4 = (cc0 - seg_begin + ld_col) * 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       ra[i] = sq ? make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w) : f;   // GDN pools x^2 (select, no branch)
     }
     // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
-    const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * P.Npad * (PK * 4));   // uniform
+    const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * u_Npad * (PK * 4));   // uniform
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_off[i] + wbase), 0, 0);
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       c_kc += has_half;                      // (g, tap, 0) -> (g, tap, 1)
       c_tap += adv_tap;
       c_tx += adv_tap;
-      const int wx = (c_tx == P.kw) ? 1 : 0;
+      const int wx = (c_tx == u_kw) ? 1 : 0;
       c_tx = wx ? 0 : c_tx;
       c_ty += wx;
       const int wt = (c_tap == n_taps) ? 1 : 0;
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     } else {
       ++c_tap;
       ++c_tx;
-      const int wx = (c_tx == P.kw) ? 1 : 0;
+      const int wx = (c_tx == u_kw) ? 1 : 0;
       c_tx = wx ? 0 : c_tx;
       c_ty += wx;
       const int wt = (c_tap == n_taps) ? 1 : 0;
@@ -241,17 +254,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       c_kc += wt;
     }
   };
+  static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
+  const int st_col = (((ld_col >> 2) ^ ((ld_row >> SW_SHIFT) & (CPR - 1))) << 2);   // swizzled float offset in the row
   auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     float* a = sA + buf * BM * LDS_LD;
     float* b = sB + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       if (A_FULL || ld_row + i * RPP < BM)
-        *reinterpret_cast<float4*>(a + (ld_row + i * RPP) * LDS_LD + ld_col) = ra[i];
+        *reinterpret_cast<float4*>(a + (ld_row + i * RPP) * LDS_LD + st_col) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       if (B_FULL || ld_row + i * RPP < BN)
-        *reinterpret_cast<float4*>(b + (ld_row + i * RPP) * LDS_LD + ld_col) = rb[i];
+        *reinterpret_cast<float4*>(b + (ld_row + i * RPP) * LDS_LD + st_col) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -263,8 +278,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  const int a_row0 = (wm * TM * 32 + l31) * LDS_LD + lh * 4;
-  const int b_row0 = (wn * TN * 32 + l31) * LDS_LD + lh * 4;
+  // rows of a wave's 32-row groups differ by multiples of 32, so the swizzle term depends on l31 only
+  const int a_row0 = (wm * TM * 32 + l31) * LDS_LD;
+  const int b_row0 = (wn * TN * 32 + l31) * LDS_LD;
+  const int rd_sw = (l31 >> SW_SHIFT) & (CPR - 1);
+  int rd_col[BK / 8];
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) rd_col[kk] = ((kk * 2 + lh) ^ rd_sw) << 2;
 
   auto compute = [&](int buf) {
     const float* a = sA + buf * BM * LDS_LD + a_row0;
@@ -274,10 +294,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       float4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + kk * 8);
+        fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[kk]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + kk * 8);
+        fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[kk]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -517,7 +537,7 @@ static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // ker
 
 template <int BM, int BN, int BK, int WGM, int WGN>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
-  constexpr size_t pipe = 2 * (BM + BN) * (BK + 4) * sizeof(float);
+  constexpr size_t pipe = 2 * (BM + BN) * BK * sizeof(float);
   constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float) + (size_t)WGM * 32 * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static bool attr_set = false;
