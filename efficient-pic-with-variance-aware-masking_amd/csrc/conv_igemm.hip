@@ -186,23 +186,30 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
 
   // chunk state (block-uniform)
   int c_ty = 0, c_tx = 0, c_kc = 0, c_tap = 0;
+  int s_begin = 0, s_end = 0, s_ld4 = 0;     // current input segment (see gload)
+  unsigned s_lo = 0, s_hi = 0;
 
   // Global -> register stage through buffer loads: 32-bit per-lane byte offsets against a
   // wave-uniform descriptor, and the halo/tail zero-fill comes from the hardware range check
   // (an offset of 2^31 is out of range and returns 0) instead of branches.
   auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
     const int cc0 = c_kc * BK;
-    // segment holding channel cc0 (unused segments end at 2^30); branch-free and explicitly uniform
-    const int c_seg = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
-    const int seg_begin = c_seg == 0 ? 0 : (c_seg == 1 ? u_se0 : (c_seg == 2 ? u_se1 : u_se2));
-    // readfirstlane makes the descriptor PROVABLY wave-uniform; without it hipcc wraps every
-    // buffer load in a waterfall loop with a vmcnt(0) in between (cdna guide T20).
-    const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[c_seg]);
-    const unsigned sp_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);          // the builtin returns a signed int:
-    const unsigned sp_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));  // keep the halves unsigned
+    // Input segment holding channel cc0.  Its descriptor is loop-carried SGPR state, reloaded (scalar loads) only
+    // when cc0 leaves [s_begin, s_end): a handful of times per tile, instead of two dependent scalar loads and
+    // their s_waitcnt between every pair of MFMA phases.
+    if (cc0 < s_begin || cc0 >= s_end) {
+      const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
+      s_begin = __builtin_amdgcn_readfirstlane(k ? P.seg_end[k - 1] : 0);
+      s_end = __builtin_amdgcn_readfirstlane(P.seg_end[k]);
+      const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
+      s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);          // the builtin returns a signed int:
+      s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));  // keep the halves unsigned
+      s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * 4;
+    }
+    const int seg_begin = s_begin;
+    const int sld4 = s_ld4;
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)sp_hi << 32) | sp_lo), 0, 0x7FFFFFFF, 0x00020000);
-    const int sld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[c_seg]) * 4;
+        reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
     const int tap_pix = c_ty * u_W + c_tx;                         // uniform
     const int col4 = (cc0 - seg_begin + ld_col) * 4;
 #pragma unroll
@@ -289,23 +296,30 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   auto compute = [&](int buf) {
     const float* a = sA + buf * BM * LDS_LD + a_row0;
     const float* b = sB + buf * BN * LDS_LD + b_row0;
+    // operand fragments are double-buffered: the ds_reads of sub-step kk+1 are issued before the MFMAs of kk,
+    // so their LDS latency hides under 4*TM*TN MFMAs instead of being waited for
+    float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[0]);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 fa[TM], fb[TN];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[kk]);
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[kk + 1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[kk]);
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[kk + 1]);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
         }
     }
   };
