@@ -546,6 +546,7 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restric
 }
 
 static int g_force[3] = {0, 0, 0};   // tuning hook: forced BM / BN / BK (0 = automatic)
+static int g_last[3] = {0, 0, 0};   // tile configuration of the most recent launch (diagnostics)
 
 static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
 
@@ -573,6 +574,13 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
 using namespace vam;
 
 extern "C" {
+
+int vam_conv_last_tile(int* bm, int* bn, int* bk) {
+  if (bm) *bm = g_last[0];
+  if (bn) *bn = g_last[1];
+  if (bk) *bk = g_last[2];
+  return VAM_OK;
+}
 
 int vam_conv_force_tile(int bm, int bn, int bk) {
   g_force[0] = bm; g_force[1] = bn; g_force[2] = bk;
@@ -734,6 +742,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }
+  g_last[0] = bm; g_last[1] = best_bn; g_last[2] = bk;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     ga.tile_start[i] = total;

@@ -133,6 +133,8 @@ int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
 int vam_conv_group(const vam_conv* problems, int n_problems, void* stream);
 /* Tuning hook: force the tile (BM in {64,128}, BN in {32,...,224}, BK in {16,32}); 0 = automatic. */
 int vam_conv_force_tile(int bm, int bn, int bk);
+/* Diagnostics: the (BM, BN, BK) the tile heuristic picked for the most recent vam_conv_group launch. */
+int vam_conv_last_tile(int* bm, int* bn, int* bk);
 
 /* ------------------------------------------------------------------ model edges */
 /* x NCHW [B,3,H,W] -> space-to-depth NHWC [B,H/2,W/2,16] (12 real channels (py,px,c), 4 zero)

@@ -9,6 +9,11 @@ SHAPES = [  # (n_problems, cin, n, k, stride, B, H, W)
     (2, 512, 224, 3, 1, 32, 16, 16), (8, 384, 224, 3, 1, 32, 16, 16), (8, 224, 176, 3, 1, 32, 16, 16),
     (4, 96, 192, 1, 1, 32, 64, 64), (4, 192, 96, 1, 1, 32, 64, 64), (2, 192, 192, 1, 1, 32, 128, 128), (2, 192, 576, 1, 1, 32, 64, 64),
 ]
+import os
+if os.environ.get("FORCE"):
+    bm, bn, bk = (int(v) for v in os.environ["FORCE"].split(","))
+    L.load().vam_conv_force_tile(bm, bn, bk)
+    SHAPES = SHAPES[:3] + SHAPES[8:10]
 for npb, cin, n, k, st, B, H, W in SHAPES:
     probs, keep = [], []
     for i in range(npb):

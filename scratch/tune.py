@@ -41,7 +41,7 @@ for (label, npb, cin, n, k, st, B, H, W) in SHAPES:
     best = []
     for bm, bn, bk in itertools.product((128, 64), (32, 64, 96, 128, 160, 192, 224), (16, 32)):
         if bk == 32 and cin % 32: continue
-        if 2 * (bm + bn) * (bk + 4) * 4 > 150000: continue
+        if 2 * (bm + bn) * bk * 4 > 163000: continue
         npad = (n + 31) // 32 * 32
         if bn > npad and bn != 32: 
             if bn - npad >= 32: continue
@@ -64,5 +64,8 @@ for (label, npb, cin, n, k, st, B, H, W) in SHAPES:
     a.record()
     for _ in range(5): ops.conv_group(probs)
     b.record(); torch.cuda.synchronize(); auto = a.elapsed_time(b) / 5
-    print(f"{label:36s} auto {auto*1e3:8.1f}us {flops/auto/1e9:6.1f}TF | " + "  ".join(f"{bm}x{bn}x{bk}:{flops/t/1e9:.0f}" for t, bm, bn, bk in best[:6]), flush=True)
+    import ctypes
+    cb = [ctypes.c_int() for _ in range(3)]
+    lib.vam_conv_last_tile(*[ctypes.byref(c) for c in cb])
+    print(f"{label:36s} auto[{cb[0].value}x{cb[1].value}x{cb[2].value}] {auto*1e3:8.1f}us {flops/auto/1e9:6.1f}TF | " + "  ".join(f"{bm}x{bn}x{bk}:{flops/t/1e9:.0f}" for t, bm, bn, bk in best[:6]), flush=True)
     del keep
