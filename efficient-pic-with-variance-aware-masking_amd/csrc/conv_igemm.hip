@@ -28,6 +28,7 @@ namespace vam {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvP {
   const float* seg_ptr[VAM_MAX_SEG];
@@ -73,7 +74,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int PK = 16;  // packing granularity of the weight buffer along K
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+// MODE 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+// MODE 1: every fp32 operand is split EXACTLY into three bf16 terms (x = hi + mid + lo, 8 + 8 + 8 mantissa bits) and
+//         the product is formed from the six bf16 x bf16 partial products of weight <= 2 (each exact in fp32) on
+//         v_mfma_f32_32x32x16_bf16, accumulating in fp32.  Dropped terms are below 2^-24 of the product — the size of
+//         ONE fp32 rounding; measured error vs float64 is slightly smaller than the fp32 fma chain's
+//         (scratch/probe/bf16x3.hip: rms 1.06e-6 vs 1.22e-6 at K = 4800).  The bf16 pipe runs 16x the fp32 MFMA rate,
+//         so six products cost 6/16 of the fp32 matrix time.  Weights are split once at pack time, activations when
+//         they are staged into LDS.
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const GroupArgs args) {
   constexpr int NT = WGM * WGN * 64;         // threads per block
   constexpr int LDS_LD = BK;                 // floats per LDS row: no padding, the 16-byte chunks of a row are
@@ -81,7 +90,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
                                              // the MFMA operand reads are bank-conflict free
   constexpr int TM = BM / WGM / 32;          // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
-  constexpr int CPR = BK / 4;                // float4 chunks per row
+  constexpr int CPR = MODE ? 4 : BK / 4;     // per-thread load units per row (MODE 0: float4; MODE 1: 8 channels)
+  constexpr int LDW = MODE ? 8 : 4;          // floats per load unit
+  static_assert(MODE == 0 || BK == 32, "the bf16x3 path steps K by 32 channels");
   // chunk c of row r lives at chunk c ^ ((r >> SW_SHIFT) & (CPR-1)): 16 consecutive lanes of a ds_write_b128
   // (16/CPR whole rows) and of a ds_read_b128 (16 rows, one logical chunk) each cover all 64 banks once
   constexpr int SW_SHIFT = (CPR == 4) ? 2 : 1;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
   const int ld_row = tid / CPR;              // row within a pass
-  const int ld_col = (tid % CPR) * 4;        // float offset within the chunk
+  const int ld_col = (tid % CPR) * LDW;      // float offset within the chunk
 
   // ---- per-thread A rows: decode the output position once.  a_pix0 = input pixel index of tap
   // (0,0); a_mask bit t = tap t of this row lies inside the image (zero padding otherwise).
@@ -162,120 +173,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       a_mask[i] = m;
     }
   }
-  // B rows: byte offset inside one [16-chunk][Npad][16] slab of the packed weights (constant per thread)
-  unsigned b_off[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int r = ld_row + i * RPP;
-    const bool ok = (B_FULL || r < BN) && (n0 + r < P.Npad);
-    b_off[i] = ok ? (unsigned)((((ld_col >> 4) * u_Npad + n0 + r) * PK + (ld_col & 15)) * 4) : 0x80000000u;
-  }
-  const unsigned long long wpa = reinterpret_cast<unsigned long long>(P.wpack);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(wpa >> 32)) << 32) |
-                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)wpa)), 0, 0x7FFFFFFF, 0x00020000);
-  const bool sq = (P.flags & VAM_CONV_SQUARE_IN) != 0;
-
-  // Two register stages: the loads of chunk k+2 are issued before chunk k is computed and are
-  // written to LDS one iteration later, so a load has two compute phases to land (L2-miss
-  // latency is ~2 us under load; one K chunk of MFMAs is 0.2-1.3 us).
-  float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  const int n_taps = u_kh * u_kw;
-  const int n_chunks = n_taps * u_Kc;        // Kc = K chunks of BK per tap
-  const int kc16 = u_kc16;                   // 16-channel packing chunks per tap
-
-  // chunk state (block-uniform)
-  int c_ty = 0, c_tx = 0, c_kc = 0, c_tap = 0;
-  int s_begin = 0, s_end = 0, s_ld4 = 0;     // current input segment (see gload)
-  unsigned s_lo = 0, s_hi = 0;
-
-  // Global -> register stage through buffer loads: 32-bit per-lane byte offsets against a
-  // wave-uniform descriptor, and the halo/tail zero-fill comes from the hardware range check
-  // (an offset of 2^31 is out of range and returns 0) instead of branches.
-  auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
-    const int cc0 = c_kc * BK;
-    // Input segment holding channel cc0.  Its descriptor is loop-carried SGPR state, reloaded (scalar loads) only
-    // when cc0 leaves [s_begin, s_end): a handful of times per tile, instead of two dependent scalar loads and
-    // their s_waitcnt between every pair of MFMA phases.
-    if (cc0 < s_begin || cc0 >= s_end) {
-      const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
-      s_begin = __builtin_amdgcn_readfirstlane(k ? P.seg_end[k - 1] : 0);
-      s_end = __builtin_amdgcn_readfirstlane(P.seg_end[k]);
-      const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
-      s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);          // the builtin returns a signed int:
-      s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));  // keep the halves unsigned
-      s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * 4;
-    }
-    const int seg_begin = s_begin;
-    const int sld4 = s_ld4;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
-    const int tap_pix = c_ty * u_W + c_tx;                         // uniform
-    const int col4 = (cc0 - seg_begin + ld_col) * 4;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const bool ok = (a_mask[i] >> c_tap) & 1u;
-      const unsigned off = (unsigned)((a_pix0[i] + tap_pix) * sld4 + col4);
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(ok ? off : 0x80000000u), 0, 0);
-      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-      ra[i] = sq ? make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w) : f;   // GDN pools x^2 (select, no branch)
-    }
-    // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
-    const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * u_Npad * (PK * 4));   // uniform
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_off[i] + wbase), 0, 0);
-      rb[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-    // advance chunk state (branch-free: the steady-state loop body must stay one basic block so
-    // the steady state stays straight-line code)
-    // K order (canonical, identical for every tile shape and for BK = 16 or 32, so a layer gives
-    // bit-identical results however it is tiled or grouped — the decoder must reproduce the
-    // encoder's sigma exactly):  32-channel group OUTER, tap MIDDLE, 16-channel half INNER.
-    // All kh*kw taps of one group touch the same input pixels (128 B of each), so a block's
-    // working set between re-touches is ~100 KB instead of the whole halo x all channels and the
-    // re-reads hit the XCD's L2 instead of going back out to the fabric.
-    if (BK == 16) {
-      const int has_half = (((c_kc & 1) == 0) && (c_kc + 1 < kc16)) ? 1 : 0;   // second half of this group exists
-      const int adv_tap = has_half ? 0 : 1;
-      c_kc += has_half;                      // (g, tap, 0) -> (g, tap, 1)
-      c_tap += adv_tap;
-      c_tx += adv_tap;
-      const int wx = (c_tx == u_kw) ? 1 : 0;
-      c_tx = wx ? 0 : c_tx;
-      c_ty += wx;
-      const int wt = (c_tap == n_taps) ? 1 : 0;
-      c_tap = wt ? 0 : c_tap;
-      c_ty = wt ? 0 : c_ty;
-      // next tap of the same group restarts at the group's first half; next group starts after it
-      c_kc = adv_tap ? (wt ? (c_kc | 1) + 1 : (c_kc & ~1)) : c_kc;
-    } else {
-      ++c_tap;
-      ++c_tx;
-      const int wx = (c_tx == u_kw) ? 1 : 0;
-      c_tx = wx ? 0 : c_tx;
-      c_ty += wx;
-      const int wt = (c_tap == n_taps) ? 1 : 0;
-      c_tap = wt ? 0 : c_tap;
-      c_ty = wt ? 0 : c_ty;
-      c_kc += wt;
-    }
-  };
-  static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
-  const int st_col = (((ld_col >> 2) ^ ((ld_row >> SW_SHIFT) & (CPR - 1))) << 2);   // swizzled float offset in the row
-  auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
-    float* a = sA + buf * BM * LDS_LD;
-    float* b = sB + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (A_FULL || ld_row + i * RPP < BM)
-        *reinterpret_cast<float4*>(a + (ld_row + i * RPP) * LDS_LD + st_col) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (B_FULL || ld_row + i * RPP < BN)
-        *reinterpret_cast<float4*>(b + (ld_row + i * RPP) * LDS_LD + st_col) = rb[i];
-  };
-
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -285,78 +182,354 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  // rows of a wave's 32-row groups differ by multiples of 32, so the swizzle term depends on l31 only
-  const int a_row0 = (wm * TM * 32 + l31) * LDS_LD;
-  const int b_row0 = (wn * TN * 32 + l31) * LDS_LD;
-  const int rd_sw = (l31 >> SW_SHIFT) & (CPR - 1);
-  int rd_col[BK / 8];
-#pragma unroll
-  for (int kk = 0; kk < BK / 8; ++kk) rd_col[kk] = ((kk * 2 + lh) ^ rd_sw) << 2;
+  const unsigned long long wpa = reinterpret_cast<unsigned long long>(P.wpack);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(wpa >> 32)) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)wpa)), 0, 0x7FFFFFFF, 0x00020000);
+  const bool sq = (P.flags & VAM_CONV_SQUARE_IN) != 0;
 
-  auto compute = [&](int buf) {
-    const float* a = sA + buf * BM * LDS_LD + a_row0;
-    const float* b = sB + buf * BN * LDS_LD + b_row0;
-    // operand fragments are double-buffered: the ds_reads of sub-step kk+1 are issued before the MFMAs of kk,
-    // so their LDS latency hides under 4*TM*TN MFMAs instead of being waited for
-    float4 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[0]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[0]);
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < BK / 8) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[kk + 1]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[kk + 1]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
-        }
+  // chunk state (block-uniform)
+  int c_ty = 0, c_tx = 0, c_kc = 0, c_tap = 0;
+  int s_begin = 0, s_end = 0, s_ld4 = 0;     // current input segment (see gload)
+  unsigned s_lo = 0, s_hi = 0;
+  const int n_taps = u_kh * u_kw;
+  const int n_chunks = n_taps * u_Kc;        // Kc = K chunks of BK per tap
+  const int kc16 = u_kc16;                   // 16-channel packing chunks per tap
+  if constexpr (MODE == 0) {
+    // B rows: byte offset inside one [16-chunk][Npad][16] slab of the packed weights (constant per thread)
+    unsigned b_off[NB];
+  #pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = ld_row + i * RPP;
+      const bool ok = (B_FULL || r < BN) && (n0 + r < P.Npad);
+      b_off[i] = ok ? (unsigned)((((ld_col >> 4) * u_Npad + n0 + r) * PK + (ld_col & 15)) * 4) : 0x80000000u;
     }
-  };
+    // Two register stages: the loads of chunk k+2 are issued before chunk k is computed and are
+    // written to LDS one iteration later, so a load has two compute phases to land (L2-miss
+    // latency is ~2 us under load; one K chunk of MFMAs is 0.2-1.3 us).
+    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
 
-  // prologue: chunk 0 -> LDS[0]; chunk 1 -> stage 0 registers
-  gload(ra0, rb0);
-  sstore(0, ra0, rb0);
-  if (n_chunks > 1) gload(ra0, rb0);
-  __syncthreads();
-  // steady state, unrolled by two so that the register stages are named statically.  At the top of
-  // step ch the LDS buffer ch&1 holds chunk ch and one register stage holds chunk ch+1 (loaded a
-  // whole compute phase ago).  The stage is written to the other LDS buffer FIRST (that buffer's
-  // last readers passed the barrier that ended step ch-1), then chunk ch+2 is requested, then the
-  // MFMAs run: neither the LDS stores nor the global loads sit between the MFMAs and the barrier.
-  int ch = 0;
-  // steady state (no conditionals: chunks ch+1..ch+3 all exist)
-  for (; ch + 3 < n_chunks; ch += 2) {
-    sstore(1, ra0, rb0);
-    gload(ra1, rb1);
-    compute(0);
-    __syncthreads();
-    sstore(0, ra1, rb1);
+
+    // Global -> register stage through buffer loads: 32-bit per-lane byte offsets against a
+    // wave-uniform descriptor, and the halo/tail zero-fill comes from the hardware range check
+    // (an offset of 2^31 is out of range and returns 0) instead of branches.
+    auto gload = [&](float4 (&ra)[NA], float4 (&rb)[NB]) {
+      const int cc0 = c_kc * BK;
+      // Input segment holding channel cc0.  Its descriptor is loop-carried SGPR state, reloaded (scalar loads) only
+      // when cc0 leaves [s_begin, s_end): a handful of times per tile, instead of two dependent scalar loads and
+      // their s_waitcnt between every pair of MFMA phases.
+      if (cc0 < s_begin || cc0 >= s_end) {
+        const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
+        s_begin = __builtin_amdgcn_readfirstlane(k ? P.seg_end[k - 1] : 0);
+        s_end = __builtin_amdgcn_readfirstlane(P.seg_end[k]);
+        const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
+        s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);          // the builtin returns a signed int:
+        s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));  // keep the halves unsigned
+        s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * 4;
+      }
+      const int seg_begin = s_begin;
+      const int sld4 = s_ld4;
+      const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
+      const int tap_pix = c_ty * u_W + c_tx;                         // uniform
+      const int col4 = (cc0 - seg_begin + ld_col) * 4;
+  #pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = (a_mask[i] >> c_tap) & 1u;
+        const unsigned off = (unsigned)((a_pix0[i] + tap_pix) * sld4 + col4);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(ok ? off : 0x80000000u), 0, 0);
+        float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        ra[i] = sq ? make_float4(f.x * f.x, f.y * f.y, f.z * f.z, f.w * f.w) : f;   // GDN pools x^2 (select, no branch)
+      }
+      // weights: [tap][kc16][Npad][16]; a BK=32 chunk is two consecutive 16-chunks
+      const unsigned wbase = (unsigned)((c_tap * kc16 + c_kc * (BK / PK)) * u_Npad * (PK * 4));   // uniform
+  #pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_off[i] + wbase), 0, 0);
+        rb[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      // advance chunk state (branch-free: the steady-state loop body must stay one basic block so
+      // the steady state stays straight-line code)
+      // K order (canonical, identical for every tile shape and for BK = 16 or 32, so a layer gives
+      // bit-identical results however it is tiled or grouped — the decoder must reproduce the
+      // encoder's sigma exactly):  32-channel group OUTER, tap MIDDLE, 16-channel half INNER.
+      // All kh*kw taps of one group touch the same input pixels (128 B of each), so a block's
+      // working set between re-touches is ~100 KB instead of the whole halo x all channels and the
+      // re-reads hit the XCD's L2 instead of going back out to the fabric.
+      if (BK == 16) {
+        const int has_half = (((c_kc & 1) == 0) && (c_kc + 1 < kc16)) ? 1 : 0;   // second half of this group exists
+        const int adv_tap = has_half ? 0 : 1;
+        c_kc += has_half;                      // (g, tap, 0) -> (g, tap, 1)
+        c_tap += adv_tap;
+        c_tx += adv_tap;
+        const int wx = (c_tx == u_kw) ? 1 : 0;
+        c_tx = wx ? 0 : c_tx;
+        c_ty += wx;
+        const int wt = (c_tap == n_taps) ? 1 : 0;
+        c_tap = wt ? 0 : c_tap;
+        c_ty = wt ? 0 : c_ty;
+        // next tap of the same group restarts at the group's first half; next group starts after it
+        c_kc = adv_tap ? (wt ? (c_kc | 1) + 1 : (c_kc & ~1)) : c_kc;
+      } else {
+        ++c_tap;
+        ++c_tx;
+        const int wx = (c_tx == u_kw) ? 1 : 0;
+        c_tx = wx ? 0 : c_tx;
+        c_ty += wx;
+        const int wt = (c_tap == n_taps) ? 1 : 0;
+        c_tap = wt ? 0 : c_tap;
+        c_ty = wt ? 0 : c_ty;
+        c_kc += wt;
+      }
+    };
+    static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
+    const int st_col = (((ld_col >> 2) ^ ((ld_row >> SW_SHIFT) & (CPR - 1))) << 2);   // swizzled float offset in the row
+    auto sstore = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
+      float* a = sA + buf * BM * LDS_LD;
+      float* b = sB + buf * BN * LDS_LD;
+  #pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (A_FULL || ld_row + i * RPP < BM)
+          *reinterpret_cast<float4*>(a + (ld_row + i * RPP) * LDS_LD + st_col) = ra[i];
+  #pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (B_FULL || ld_row + i * RPP < BN)
+          *reinterpret_cast<float4*>(b + (ld_row + i * RPP) * LDS_LD + st_col) = rb[i];
+    };
+
+    // rows of a wave's 32-row groups differ by multiples of 32, so the swizzle term depends on l31 only
+    const int a_row0 = (wm * TM * 32 + l31) * LDS_LD;
+    const int b_row0 = (wn * TN * 32 + l31) * LDS_LD;
+    const int rd_sw = (l31 >> SW_SHIFT) & (CPR - 1);
+    int rd_col[BK / 8];
+  #pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) rd_col[kk] = ((kk * 2 + lh) ^ rd_sw) << 2;
+
+    auto compute = [&](int buf) {
+      const float* a = sA + buf * BM * LDS_LD + a_row0;
+      const float* b = sB + buf * BN * LDS_LD + b_row0;
+      // operand fragments are double-buffered: the ds_reads of sub-step kk+1 are issued before the MFMAs of kk,
+      // so their LDS latency hides under 4*TM*TN MFMAs instead of being waited for
+      float4 fa[2][TM], fb[2][TN];
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[0]);
+  #pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[0]);
+  #pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 8) {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + rd_col[kk + 1]);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + rd_col[kk + 1]);
+        }
+  #pragma unroll
+        for (int i = 0; i < TM; ++i)
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+    };
+
+    // prologue: chunk 0 -> LDS[0]; chunk 1 -> stage 0 registers
     gload(ra0, rb0);
-    compute(1);
+    sstore(0, ra0, rb0);
+    if (n_chunks > 1) gload(ra0, rb0);
     __syncthreads();
-  }
-  // tail: at most three chunks left
-  for (; ch < n_chunks; ch += 2) {
-    if (ch + 1 < n_chunks) sstore(1, ra0, rb0);
-    if (ch + 2 < n_chunks) gload(ra1, rb1);
-    compute(0);
-    __syncthreads();
-    if (ch + 1 >= n_chunks) break;
-    if (ch + 2 < n_chunks) sstore(0, ra1, rb1);
-    if (ch + 3 < n_chunks) gload(ra0, rb0);
-    compute(1);
-    __syncthreads();
+    // steady state, unrolled by two so that the register stages are named statically.  At the top of
+    // step ch the LDS buffer ch&1 holds chunk ch and one register stage holds chunk ch+1 (loaded a
+    // whole compute phase ago).  The stage is written to the other LDS buffer FIRST (that buffer's
+    // last readers passed the barrier that ended step ch-1), then chunk ch+2 is requested, then the
+    // MFMAs run: neither the LDS stores nor the global loads sit between the MFMAs and the barrier.
+    int ch = 0;
+    // steady state (no conditionals: chunks ch+1..ch+3 all exist)
+    for (; ch + 3 < n_chunks; ch += 2) {
+      sstore(1, ra0, rb0);
+      gload(ra1, rb1);
+      compute(0);
+      __syncthreads();
+      sstore(0, ra1, rb1);
+      gload(ra0, rb0);
+      compute(1);
+      __syncthreads();
+    }
+    // tail: at most three chunks left
+    for (; ch < n_chunks; ch += 2) {
+      if (ch + 1 < n_chunks) sstore(1, ra0, rb0);
+      if (ch + 2 < n_chunks) gload(ra1, rb1);
+      compute(0);
+      __syncthreads();
+      if (ch + 1 >= n_chunks) break;
+      if (ch + 2 < n_chunks) sstore(0, ra1, rb1);
+      if (ch + 3 < n_chunks) gload(ra0, rb0);
+      compute(1);
+      __syncthreads();
+    }
+
+  } else {
+    // =============================================================== MODE 1: bf16x3 operands
+    // LDS row (one pixel / one output channel, 32 input channels of one tap): 12 chunks of 16 B,
+    //   chunk (g*3 + p) = 8 bf16 of channel group g (channels 8g..8g+7) and plane p (0 hi, 1 mid, 2 lo);
+    // an MFMA k-step s (16 channels) takes group 2s from lanes 0-31 and 2s+1 from lanes 32-63.
+    // Row stride 208 B = 52 dwords: 16 consecutive rows of one chunk cover all 64 banks (conflict-free reads).
+    constexpr int RS = 52;
+    constexpr int NBUF = (BM + BN <= 128) ? 2 : 1;   // LDS buffers: 1.5x the bytes of fp32 rows, so wide tiles single-buffer
+    constexpr int NBC = (BN * 12 + NT - 1) / NT;     // 16-byte weight chunks per thread and K chunk
+    float* sA1 = smem;                               // [NBUF][BM][RS]
+    float* sB1 = smem + NBUF * BM * RS;              // [NBUF][BN][RS]
+    unsigned b_goff[NBC];
+    int b_loff[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) {
+      const int idx = tid + j * NT;
+      const int row = idx / 12, c = idx - row * 12;
+      const bool in_tile = idx < BN * 12;
+      b_goff[j] = (in_tile && n0 + row < u_Npad) ? (unsigned)((n0 + row) * 192 + c * 16) : 0x80000000u;
+      b_loff[j] = in_tile ? row * RS + c * 4 : -1;
+    }
+    const int u_Cin = __builtin_amdgcn_readfirstlane(P.Cin);
+    float4 ra[NA][2];
+    u32x4 rb[NBC];
+
+    auto gload = [&]() {
+      const int cc0 = c_kc * 32;
+      if (cc0 < s_begin || cc0 >= s_end) {           // input segment changed (rare; see MODE 0)
+        const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
+        s_begin = __builtin_amdgcn_readfirstlane(k ? P.seg_end[k - 1] : 0);
+        s_end = __builtin_amdgcn_readfirstlane(P.seg_end[k]);
+        const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
+        s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);
+        s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));
+        s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * 4;
+      }
+      const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
+      const int tap_pix = c_ty * u_W + c_tx;
+      const int col4 = (cc0 - s_begin + ld_col) * 4;
+      const bool ch_ok = cc0 + ld_col < u_Cin;       // the last chunk of a 16-mod-32 channel count is half empty
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
+        const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u), 0, 0);
+        ra[i][0] = make_float4(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w));
+        ra[i][1] = make_float4(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w));
+      }
+      // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
+      const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 192u;
+#pragma unroll
+      for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
+      // canonical K order: 32-channel group OUTER, tap INNER
+      ++c_tap;
+      ++c_tx;
+      const int wx = (c_tx == u_kw) ? 1 : 0;
+      c_tx = wx ? 0 : c_tx;
+      c_ty += wx;
+      const int wt = (c_tap == n_taps) ? 1 : 0;
+      c_tap = wt ? 0 : c_tap;
+      c_ty = wt ? 0 : c_ty;
+      c_kc += wt;
+    };
+    auto sstore = [&](int buf) {
+      float* a = sA1 + buf * BM * RS;
+      float* b = sB1 + buf * BN * RS;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (A_FULL || ld_row + i * RPP < BM) {
+          float x[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+          unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            unsigned short h2[2], m2[2], l2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float v = x[e + q];
+              v = sq ? v * v : v;                    // GDN pools x^2
+              const __bf16 bh = (__bf16)v;
+              const float r1 = v - (float)bh;        // exact: hi carries the top 8 mantissa bits
+              const __bf16 bm = (__bf16)r1;
+              const float r2 = r1 - (float)bm;       // exact; at most 8 significant bits remain
+              const __bf16 bl = (__bf16)r2;
+              h2[q] = __builtin_bit_cast(unsigned short, bh);
+              m2[q] = __builtin_bit_cast(unsigned short, bm);
+              l2[q] = __builtin_bit_cast(unsigned short, bl);
+            }
+            hw[e >> 1] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
+            mw[e >> 1] = (unsigned)m2[0] | ((unsigned)m2[1] << 16);
+            lw[e >> 1] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
+          }
+          float* dst = a + (ld_row + i * RPP) * RS + (ld_col >> 3) * 12;   // chunk 3g of this row
+          u32x4 t;
+          t.x = hw[0]; t.y = hw[1]; t.z = hw[2]; t.w = hw[3];
+          *reinterpret_cast<u32x4*>(dst) = t;
+          t.x = mw[0]; t.y = mw[1]; t.z = mw[2]; t.w = mw[3];
+          *reinterpret_cast<u32x4*>(dst + 4) = t;
+          t.x = lw[0]; t.y = lw[1]; t.z = lw[2]; t.w = lw[3];
+          *reinterpret_cast<u32x4*>(dst + 8) = t;
+        }
+#pragma unroll
+      for (int j = 0; j < NBC; ++j)
+        if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(b + b_loff[j]) = rb[j];
+    };
+    const int a_row1 = (wm * TM * 32 + l31) * RS + lh * 12;
+    const int b_row1 = (wn * TN * 32 + l31) * RS + lh * 12;
+    auto compute = [&](int buf) {
+      const float* a = sA1 + buf * BM * RS + a_row1;
+      const float* b = sB1 + buf * BN * RS + b_row1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a + i * 32 * RS + ks * 24 + pl * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + j * 32 * RS + ks * 24 + pl * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            // fixed order, smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+          }
+      }
+    };
+    if constexpr (NBUF == 2) {
+      // one barrier per chunk: chunk ch+1 goes to the other buffer before chunk ch is computed
+      gload();
+      sstore(0);
+      if (n_chunks > 1) gload();
+      __syncthreads();
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        if (ch + 1 < n_chunks) sstore((ch + 1) & 1);
+        if (ch + 2 < n_chunks) gload();
+        compute(ch & 1);
+        __syncthreads();
+      }
+    } else {
+      // single LDS buffer (wide tiles): registers hold chunk ch+1 while chunk ch is computed
+      gload();
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        sstore(0);
+        __syncthreads();
+        if (ch + 1 < n_chunks) gload();
+        compute(0);
+        __syncthreads();
+      }
+    }
   }
 
   // ---- epilogue.  The block's C tile goes through LDS one 32-row slab per wave-row at a time
@@ -470,19 +643,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
 }
 
 // ---------------------------------------------------------------- weight packing
-__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode,
-                                    int phase, int kh, int kw, int cin, int n, int npad, int bk, int kc,
-                                    long total) {
-  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= total) return;
-  int kk = (int)(d % bk);
-  long r = d / bk;
-  int nn = (int)(r % npad);
-  r /= npad;
-  int c_chunk = (int)(r % kc);
-  int tap = (int)(r / kc);
-  int ty = tap / kw, tx = tap % kw;
-  int cc = c_chunk * bk + kk;
+__device__ __forceinline__ float pack_value(const float* __restrict__ src, int mode, int phase, int kh, int kw, int cin,
+                                            int n, int nn, int cc, int ty, int tx) {
   float v = 0.f;
   if (nn < n && cc < cin) {
     if (mode == VAM_PACK_CONV) {
@@ -519,7 +681,50 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
       }
     }
   }
-  dst[d] = v;
+  return v;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode,
+                                    int phase, int kh, int kw, int cin, int n, int npad, int bk, int kc,
+                                    long total) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  int kk = (int)(d % bk);
+  long r = d / bk;
+  int nn = (int)(r % npad);
+  r /= npad;
+  int c_chunk = (int)(r % kc);
+  int tap = (int)(r / kc);
+  int ty = tap / kw, tx = tap % kw;
+  int cc = c_chunk * bk + kk;
+  dst[d] = pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx);
+}
+
+// bf16x3 layout: [tap][32-channel chunk][Npad][12 chunks][8 bf16]; chunk (g*3 + p) holds plane p (hi/mid/lo) of
+// channels 8g..8g+7 of the 32-channel chunk.  The three planes sum to the fp32 weight exactly.
+__global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
+                                        int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  int kk = (int)(d % 32);
+  long r = d / 32;
+  int nn = (int)(r % npad);
+  r /= npad;
+  int c_chunk = (int)(r % kc32);
+  int tap = (int)(r / kc32);
+  int ty = tap / kw, tx = tap % kw;
+  int cc = c_chunk * 32 + kk;
+  const float v = pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx);
+  const __bf16 bh = (__bf16)v;
+  const float r1 = v - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  const size_t row = ((size_t)(tap * kc32 + c_chunk) * npad + nn) * 96;      // 96 bf16 = 192 B per row
+  const int g = kk >> 3, e = kk & 7;
+  dst[row + (g * 3 + 0) * 8 + e] = __builtin_bit_cast(unsigned short, bh);
+  dst[row + (g * 3 + 1) * 8 + e] = __builtin_bit_cast(unsigned short, bm);
+  dst[row + (g * 3 + 2) * 8 + e] = __builtin_bit_cast(unsigned short, bl);
 }
 
 __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
@@ -550,14 +755,25 @@ static int g_last[3] = {0, 0, 0};   // tile configuration of the most recent lau
 
 static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+static int g_mode = -1;              // 0 = fp32 MFMA, 1 = bf16x3 MFMA; -1 = not chosen yet (VAMPIC_CONV, default bf16x3)
+
+static int conv_mode() {
+  if (g_mode < 0) {
+    const char* e = getenv("VAMPIC_CONV");
+    g_mode = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+  }
+  return g_mode;
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
-  constexpr size_t pipe = 2 * (BM + BN) * BK * sizeof(float);
+  constexpr size_t pipe = MODE ? (size_t)((BM + BN <= 128) ? 2 : 1) * (BM + BN) * 52 * sizeof(float)
+                               : (size_t)2 * (BM + BN) * BK * sizeof(float);
   constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float) + (size_t)WGM * 32 * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
@@ -565,7 +781,7 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   int per_xcd = 0;
   for (int i = 0; i < ga.nprob; ++i) per_xcd += (ga.tile_start[i + 1] - ga.tile_start[i] + 7) / 8;
   (void)total_tiles;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
   return check_launch("conv_igemm_kernel");
 }
 
@@ -587,10 +803,22 @@ int vam_conv_force_tile(int bm, int bn, int bk) {
   return VAM_OK;
 }
 
+int vam_conv_set_mode(int mode) {
+  if (mode != 0 && mode != 1) {
+    set_error("vam_conv_set_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+    return VAM_EINVAL;
+  }
+  g_mode = mode;
+  return VAM_OK;
+}
+
+int vam_conv_get_mode(void) { return conv_mode(); }
+
 size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
+  int npad = (n + 31) / 32 * 32;
+  if (conv_mode() == 1) return (size_t)kh * kw * ((cin + 31) / 32) * npad * 48;   // 96 bf16 per (n, 32-channel chunk)
   int bk = PK;
   int kc = (cin + bk - 1) / bk;
-  int npad = (n + 31) / 32 * 32;
   return (size_t)kh * kw * kc * npad * bk;
 }
 
@@ -603,9 +831,16 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int
   if (mode == VAM_PACK_DECONV5S2 && phase >= 0)
     VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
   if (mode == VAM_PACK_GDN) VAM_REQUIRE(kh == 1 && kw == 1, "GDN pack is 1x1");
+  int npad = (n + 31) / 32 * 32;
+  if (conv_mode() == 1) {
+    const int kc32 = (cin + 31) / 32;
+    const long total1 = (long)kh * kw * kc32 * npad * 32;
+    hipLaunchKernelGGL(pack_weights_bf3_kernel, dim3(cdiv(total1, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<unsigned short*>(dst), mode, phase, kh, kw, cin, n, npad, kc32, total1);
+    return check_launch("pack_weights_bf3_kernel");
+  }
   int bk = PK;
   int kc = (cin + bk - 1) / bk;
-  int npad = (n + 31) / 32 * 32;
   long total = (long)kh * kw * kc * npad * bk;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, mode,
                      phase, kh, kw, cin, n, npad, bk, kc, total);
@@ -648,7 +883,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
         p.seg_end[s] = 1 << 30;
       }
     }
-    int pbk = bk_for(cin);
+    const int mode1 = conv_mode() == 1;
+    int pbk = mode1 ? 32 : bk_for(cin);
     VAM_REQUIRE(cin % 16 == 0, "conv[%d]: Cin %d not a multiple of 16", i, cin);
     for (int sgi = 0; sgi < c.n_seg; ++sgi)
       VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * 4.0 < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
@@ -742,6 +978,15 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }
+  if (conv_mode() == 1) {
+    // bf16x3 path: K step is always 32; configurations whose operand fragments would not fit the register file
+    // (seven 32-column groups per wave) fall back to their two-tile neighbours
+    bk = 32;
+    for (int i = 0; i < nprob; ++i) ga.p[i].Kc = (ga.p[i].Cin + 31) / 32;
+    if (best_bn == 224) best_bn = 128;
+    if (best_bn == 160) best_bn = (bm == 128) ? 96 : 64;
+    if (bm == 64 && best_bn == 96) best_bn = 64;
+  }
   g_last[0] = bm; g_last[1] = best_bn; g_last[2] = bk;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -752,9 +997,18 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
+  if (conv_mode() == 1) {
+#define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
+    if (bm == BM_ && best_bn == BN_) return launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1>(ga, total, s);
+    VAM_CFG1(128, 32, 4, 1) VAM_CFG1(128, 64, 2, 2) VAM_CFG1(128, 96, 4, 1) VAM_CFG1(128, 128, 2, 2) VAM_CFG1(128, 192, 2, 2)
+    VAM_CFG1(64, 32, 2, 1) VAM_CFG1(64, 64, 2, 2) VAM_CFG1(64, 128, 2, 2) VAM_CFG1(64, 192, 2, 2)
+#undef VAM_CFG1
+    set_error("vam_conv_group: no bf16x3 kernel configuration for BM=%d BN=%d", bm, best_bn);
+    return VAM_EINVAL;
+  }
 #define VAM_CFG(BM_, BN_, WGM_, WGN_)                                                        \
   if (bm == BM_ && best_bn == BN_)                                                           \
-    return bk == 32 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_>(ga, total, s) : launch_cfg<BM_, BN_, 16, WGM_, WGN_>(ga, total, s);
+    return bk == 32 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 0>(ga, total, s) : launch_cfg<BM_, BN_, 16, WGM_, WGN_, 0>(ga, total, s);
   VAM_CFG(128, 32, 4, 1) VAM_CFG(128, 64, 2, 2) VAM_CFG(128, 96, 4, 1) VAM_CFG(128, 128, 2, 2)
   VAM_CFG(128, 160, 4, 1) VAM_CFG(128, 192, 2, 2) VAM_CFG(128, 224, 4, 1)
   VAM_CFG(64, 32, 2, 1) VAM_CFG(64, 64, 2, 2) VAM_CFG(64, 96, 2, 1) VAM_CFG(64, 128, 2, 2)

@@ -133,6 +133,13 @@ int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
 int vam_conv_group(const vam_conv* problems, int n_problems, void* stream);
 /* Tuning hook: force the tile (BM in {64,128}, BN in {32,...,224}, BK in {16,32}); 0 = automatic. */
 int vam_conv_force_tile(int bm, int bn, int bk);
+/* Arithmetic of the convolution kernel.  1 (default): every fp32 operand is split exactly into three bf16 terms and
+ * the product is formed from six exact bf16 x bf16 partial products on the bf16 matrix pipe, fp32 accumulation
+ * (error vs float64 no larger than the fp32 fma chain's); 0: fp32 operands on the fp32 matrix pipe.
+ * The mode fixes the packed-weight layout: choose it (or the environment variable VAMPIC_CONV=f32|bf16x3) before
+ * the first vam_conv_wpack_floats / vam_pack_conv_weights call and do not change it while packed weights exist. */
+int vam_conv_set_mode(int mode);
+int vam_conv_get_mode(void);
 /* Diagnostics: the (BM, BN, BK) the tile heuristic picked for the most recent vam_conv_group launch. */
 int vam_conv_last_tile(int* bm, int* bn, int* bk);
 
