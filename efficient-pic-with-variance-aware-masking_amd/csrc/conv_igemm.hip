@@ -947,26 +947,33 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     int kt = ga.p[i].Cin * ga.p[i].kh * ga.p[i].kw;
     if (kt > ktot_max) ktot_max = kt;
   }
+  // bf16x3 mode: nine configurations (the wave tile needs 12 operand registers per 32 rows / columns and K step), own fit
+  static const Cand cands1[9] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
+                                 {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}};
+  const bool m1 = conv_mode() == 1;
+  const Cand* cand = m1 ? cands1 : cands;
+  const int n_cand = m1 ? 9 : 14;
+  const double b512 = m1 ? 1.018 : 1.04, b256 = m1 ? 1.097 : 1.10, k96 = m1 ? 1.084 : 1.1;
   int bm = 128, best_bn = 128;
   double best_score = -1.0;
-  for (int c = 0; c < 14; ++c) {
+  for (int c = 0; c < n_cand; ++c) {
     double padded = 0.0, real = 0.0;
     long blocks = 0;
     for (int i = 0; i < nprob; ++i) {
-      long tm_ = cdiv(ga.p[i].P, cands[c].bm), tn_ = cdiv(ga.p[i].Npad, cands[c].bn);
+      long tm_ = cdiv(ga.p[i].P, cand[c].bm), tn_ = cdiv(ga.p[i].Npad, cand[c].bn);
       blocks += tm_ * tn_;
-      padded += (double)tm_ * cands[c].bm * tn_ * cands[c].bn;
+      padded += (double)tm_ * cand[c].bm * tn_ * cand[c].bn;
       real += (double)ga.p[i].P * ga.p[i].N;
     }
-    double bp = blocks >= 1024 ? 1.0 : blocks >= 512 ? 1.04 : blocks >= 256 ? 1.10 : 1.10 * 256.0 / (double)blocks;
+    double bp = blocks >= 1024 ? 1.0 : blocks >= 512 ? b512 : blocks >= 256 ? b256 : b256 * 256.0 / (double)blocks;
     // the widest tiles run two blocks per CU: below 512 blocks part of the chip holds a single
     // 4-wave block per CU and the launch runs at that block's pace
-    if (cands[c].bm == 128 && cands[c].bn >= 160 && blocks < 512) bp *= 1.18;
+    if (cand[c].bm == 128 && cand[c].bn >= 160 && blocks < 512) bp *= 1.18;
     double kp = 1.0;
-    if (ktot_max <= 256 && cands[c].bn > 96) kp = 1.3;
-    if (ktot_max <= 256 && cands[c].bn == 96) kp = 1.1;
-    double sc = padded / real * bp * cands[c].shape * kp;
-    if (best_score < 0 || sc < best_score) { best_score = sc; bm = cands[c].bm; best_bn = cands[c].bn; }
+    if (ktot_max <= 256 && cand[c].bn > 96) kp = 1.3;
+    if (ktot_max <= 256 && cand[c].bn == 96) kp = k96;
+    double sc = padded / real * bp * cand[c].shape * kp;
+    if (best_score < 0 || sc < best_score) { best_score = sc; bm = cand[c].bm; best_bn = cand[c].bn; }
   }
   if (g_force[0] == 64 || g_force[0] == 128) bm = g_force[0];
   if (g_force[1] > 0) best_bn = g_force[1];
@@ -983,7 +990,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     // (seven 32-column groups per wave) fall back to their two-tile neighbours
     bk = 32;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = (ga.p[i].Cin + 31) / 32;
-    if (best_bn == 224) best_bn = 128;
+    if (best_bn == 224) best_bn = 128;                 // (only reachable through vam_conv_force_tile)
     if (best_bn == 160) best_bn = (bm == 128) ? 96 : 64;
     if (bm == 64 && best_bn == 96) best_bn = 64;
   }

@@ -39,9 +39,10 @@ for (label, npb, cin, n, k, st, B, H, W) in SHAPES:
         probs.append(ops.conv_problem(m.packed(), [x], o, L.ACT_GELU)); keep += [m, x, o]
     flops = 2.0 * npb * B * (H // st) * (W // st) * n * cin * k * k
     best = []
-    for bm, bn, bk in itertools.product((128, 64), (32, 64, 96, 128, 160, 192, 224), (16, 32)):
-        if bk == 32 and cin % 32: continue
-        if 2 * (bm + bn) * bk * 4 > 163000: continue
+    mode1 = lib.vam_conv_get_mode() == 1
+    for bm, bn, bk in itertools.product((128, 64), (32, 64, 96, 128, 160, 192, 224), (32,) if mode1 else (16, 32)):
+        if bk == 32 and cin % 32 and not mode1: continue
+        if mode1 and (bm, bn) not in ((128,32),(128,64),(128,96),(128,128),(128,192),(64,32),(64,64),(64,128),(64,192)): continue
         npad = (n + 31) // 32 * 32
         if bn > npad and bn != 32: 
             if bn - npad >= 32: continue
