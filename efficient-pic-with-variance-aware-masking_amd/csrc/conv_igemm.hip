@@ -443,26 +443,27 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       for (int i = 0; i < NA; ++i)
         if (A_FULL || ld_row + i * RPP < BM) {
           float x[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+          if (sq) {                                  // GDN pools x^2 (block-uniform branch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = x[e] * x[e];
+          }
+          // exact 3-way split by truncation: hi = top 16 bits of x, mid = top 16 bits of (x - hi), lo = x - hi - mid
+          // (at most 8 significant bits are left, so its top 16 bits hold it exactly); two AND + two SUB per element
+          // and one byte-permute per plane and element pair
+          unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            hb[e] = __float_as_uint(x[e]);
+            const float r1 = x[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
+            mb[e] = __float_as_uint(r1);
+            lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e] & 0xFFFF0000u));
+          }
           unsigned hw[4], mw[4], lw[4];
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            unsigned short h2[2], m2[2], l2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              float v = x[e + q];
-              v = sq ? v * v : v;                    // GDN pools x^2
-              const __bf16 bh = (__bf16)v;
-              const float r1 = v - (float)bh;        // exact: hi carries the top 8 mantissa bits
-              const __bf16 bm = (__bf16)r1;
-              const float r2 = r1 - (float)bm;       // exact; at most 8 significant bits remain
-              const __bf16 bl = (__bf16)r2;
-              h2[q] = __builtin_bit_cast(unsigned short, bh);
-              m2[q] = __builtin_bit_cast(unsigned short, bm);
-              l2[q] = __builtin_bit_cast(unsigned short, bl);
-            }
-            hw[e >> 1] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
-            mw[e >> 1] = (unsigned)m2[0] | ((unsigned)m2[1] << 16);
-            lw[e >> 1] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
+          for (int q = 0; q < 4; ++q) {
+            hw[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);   // {hi16(odd), hi16(even)}
+            mw[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
+            lw[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
           }
           float* dst = a + (ld_row + i * RPP) * RS + (ld_col >> 3) * 12;   // chunk 3g of this row
           u32x4 t;
@@ -715,16 +716,16 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   int ty = tap / kw, tx = tap % kw;
   int cc = c_chunk * 32 + kk;
   const float v = pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx);
-  const __bf16 bh = (__bf16)v;
-  const float r1 = v - (float)bh;
-  const __bf16 bm = (__bf16)r1;
-  const float r2 = r1 - (float)bm;
-  const __bf16 bl = (__bf16)r2;
+  // exact split by truncation (same as the activations' in the kernel): hi + mid + lo == v
+  const unsigned hb = __float_as_uint(v);
+  const float r1 = v - __uint_as_float(hb & 0xFFFF0000u);
+  const unsigned mb = __float_as_uint(r1);
+  const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb & 0xFFFF0000u));
   const size_t row = ((size_t)(tap * kc32 + c_chunk) * npad + nn) * 96;      // 96 bf16 = 192 B per row
   const int g = kk >> 3, e = kk & 7;
-  dst[row + (g * 3 + 0) * 8 + e] = __builtin_bit_cast(unsigned short, bh);
-  dst[row + (g * 3 + 1) * 8 + e] = __builtin_bit_cast(unsigned short, bm);
-  dst[row + (g * 3 + 2) * 8 + e] = __builtin_bit_cast(unsigned short, bl);
+  dst[row + (g * 3 + 0) * 8 + e] = (unsigned short)(hb >> 16);
+  dst[row + (g * 3 + 1) * 8 + e] = (unsigned short)(mb >> 16);
+  dst[row + (g * 3 + 2) * 8 + e] = (unsigned short)(lb >> 16);
 }
 
 __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
