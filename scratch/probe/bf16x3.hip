@@ -32,11 +32,11 @@ __global__ void k_bf16(const float* A, const float* B, float* C, int K) {
     for (int e = 0; e < 8; ++e) {
       float x = A[l31 * K + k + lh * 8 + e], y = B[l31 * K + k + lh * 8 + e];
       unsigned short xh = bf16_rn(x); float r1 = x - bf16_f(xh);
-      unsigned short xm = bf16_rn(r1); float r2 = r1 - bf16_f(xm);
-      unsigned short xl = bf16_rn(r2);
-      unsigned short yh = bf16_rn(y); float s1 = y - bf16_f(yh);
-      unsigned short ym = bf16_rn(s1); float s2 = s1 - bf16_f(ym);
-      unsigned short yl = bf16_rn(s2);
+      unsigned short xm = (unsigned short)(__float_as_uint(r1) >> 16); float r2 = r1 - bf16_f(xm);
+      unsigned short xl = (unsigned short)(__float_as_uint(r2) >> 16);
+      unsigned short yh = (unsigned short)(__float_as_uint(y) >> 16); float s1 = y - bf16_f(yh);
+      unsigned short ym = (unsigned short)(__float_as_uint(s1) >> 16); float s2 = s1 - bf16_f(ym);
+      unsigned short yl = (unsigned short)(__float_as_uint(s2) >> 16);
       unsigned short xs[3] = {xh, xm, xl}, ys[3] = {yh, ym, yl};
       for (int p = 0; p < 3; ++p) {
         a[p][e] = __builtin_bit_cast(__bf16, xs[p]);

@@ -222,3 +222,39 @@ def test_conv_result_is_independent_of_tiling():
                 lib.vam_conv_force_tile(0, 0, 0)
         for o in outs[1:]:
             assert torch.equal(o, outs[0]), (cin, n, k, st)
+
+
+def test_conv_accuracy_against_float64():
+    """The convolution kernel against a float64 convolution of the same fp32 inputs.  The default kernel splits every
+    fp32 operand exactly into three bf16 terms and sums six exact partial products in fp32, so
+    what remains is the rounding of a length-K fp32 accumulation: rms error <= (0.5 sqrt(K) + 2) * 2^-24 * rms(out),
+    the random-walk size of a sequential fp32 fma chain (what the fp32-operand kernel produces; ATen's blocked CPU
+    summation, printed for context, is a few times tighter than any sequential chain)."""
+    for cin, n, k, hw in ((512, 224, 3, (16, 16)), (192, 192, 5, (24, 24)), (96, 192, 1, (16, 16))):
+        m = Ly.Conv2d(cin, n, k, 1)
+        sd = _fill(m, 31)
+        x = _rand((2, cin) + hw, 32, 2.0)
+        truth = F.conv2d(x.double(), sd["weight"].double(), sd["bias"].double(), padding=k // 2)
+        e32 = (F.conv2d(x, sd["weight"], sd["bias"], padding=k // 2).double() - truth).pow(2).mean().sqrt().item()
+        with torch.no_grad():
+            got = m.cuda()(x.cuda()).cpu().double()
+        e_gpu = (got - truth).pow(2).mean().sqrt().item()
+        print(f"conv {cin}->{n} k{k}: rms error vs float64: fp32 ATen {e32:.3e}, kernel {e_gpu:.3e} (output rms {truth.pow(2).mean().sqrt().item():.3e})")
+        bound = (0.5 * math.sqrt(cin * k * k) + 2.0) * 2.0 ** -24 * truth.pow(2).mean().sqrt().item()
+        assert e_gpu <= bound, (cin, n, k, e_gpu, bound)
+
+
+def test_fp32_matrix_pipe_mode_in_a_child_process():
+    """VAMPIC_CONV=f32 selects the fp32-operand kernel (v_mfma_f32_32x32x2_f32).  The mode fixes the packed-weight
+    layout for the life of a process, so the fp32 arithmetic is exercised in a child: the convolution tests must
+    pass there as well."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VAMPIC_CONV="f32")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "conv2d or deconv or gdn or tiling or float64 or rem_block"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
