@@ -373,11 +373,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
 
   } else {
     // =============================================================== MODE 1: bf16x3 operands
-    // LDS row (one pixel / one output channel, 32 input channels of one tap): 12 chunks of 16 B,
-    //   chunk (g*3 + p) = 8 bf16 of channel group g (channels 8g..8g+7) and plane p (0 hi, 1 mid, 2 lo);
-    // an MFMA k-step s (16 channels) takes group 2s from lanes 0-31 and 2s+1 from lanes 32-63.
-    // Row stride 208 B = 52 dwords: 16 consecutive rows of one chunk cover all 64 banks (conflict-free reads).
-    constexpr int RS = 52;
+    // LDS row (one pixel / one output channel, 32 input channels of one tap): 12 chunks of 16 B = 192 B, no padding;
+    //   logical chunk (p*4 + g) = 8 bf16 of plane p (0 hi, 1 mid, 2 lo) and channel group g (channels 8g..8g+7),
+    //   stored at chunk p*4 + (g ^ ((row >> 2) & 3)).  An MFMA k-step s (16 channels) takes group 2s from lanes 0-31
+    //   and 2s+1 from lanes 32-63.  With the XOR term both the staging writes (16 lanes = 4 rows x 4 groups of one
+    //   plane) and the operand reads (16 rows of one chunk) touch every LDS bank exactly once.
+    constexpr int RS = 48;
     constexpr int NBUF = (BM + BN <= 128) ? 2 : 1;   // LDS buffers: 1.5x the bytes of fp32 rows, so wide tiles single-buffer
     constexpr int NBC = (BN * 12 + NT - 1) / NT;     // 16-byte weight chunks per thread and K chunk
     float* sA1 = smem;                               // [NBUF][BM][RS]
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       const int row = idx / 12, c = idx - row * 12;
       const bool in_tile = idx < BN * 12;
       b_goff[j] = (in_tile && n0 + row < u_Npad) ? (unsigned)((n0 + row) * 192 + c * 16) : 0x80000000u;
-      b_loff[j] = in_tile ? row * RS + c * 4 : -1;
+      b_loff[j] = in_tile ? row * RS + ((c & ~3) | ((c & 3) ^ ((row >> 2) & 3))) * 4 : -1;
     }
     const int u_Cin = __builtin_amdgcn_readfirstlane(P.Cin);
     float4 ra[NA][2];
@@ -436,6 +437,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       c_ty = wt ? 0 : c_ty;
       c_kc += wt;
     };
+    static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
+    const int st1_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
     auto sstore = [&](int buf) {
       float* a = sA1 + buf * BM * RS;
       float* b = sB1 + buf * BN * RS;
@@ -465,21 +468,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
             mw[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
             lw[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
           }
-          float* dst = a + (ld_row + i * RPP) * RS + (ld_col >> 3) * 12;   // chunk 3g of this row
+          float* dst = a + (ld_row + i * RPP) * RS + st1_col;             // swizzled chunk of plane 0; planes are 16 floats apart
           u32x4 t;
           t.x = hw[0]; t.y = hw[1]; t.z = hw[2]; t.w = hw[3];
           *reinterpret_cast<u32x4*>(dst) = t;
           t.x = mw[0]; t.y = mw[1]; t.z = mw[2]; t.w = mw[3];
-          *reinterpret_cast<u32x4*>(dst + 4) = t;
+          *reinterpret_cast<u32x4*>(dst + 16) = t;
           t.x = lw[0]; t.y = lw[1]; t.z = lw[2]; t.w = lw[3];
-          *reinterpret_cast<u32x4*>(dst + 8) = t;
+          *reinterpret_cast<u32x4*>(dst + 32) = t;
         }
 #pragma unroll
       for (int j = 0; j < NBC; ++j)
         if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(b + b_loff[j]) = rb[j];
     };
-    const int a_row1 = (wm * TM * 32 + l31) * RS + lh * 12;
-    const int b_row1 = (wn * TN * 32 + l31) * RS + lh * 12;
+    const int a_row1 = (wm * TM * 32 + l31) * RS;
+    const int b_row1 = (wn * TN * 32 + l31) * RS;
+    const int rsw = (l31 >> 2) & 3;                  // rows of a wave's 32-row groups differ by multiples of 32
+    const int rd1[2] = {((lh ^ rsw) << 2), (((2 + lh) ^ rsw) << 2)};
     auto compute = [&](int buf) {
       const float* a = sA1 + buf * BM * RS + a_row1;
       const float* b = sB1 + buf * BN * RS + b_row1;
@@ -489,11 +494,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a + i * 32 * RS + ks * 24 + pl * 4);
+          for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a + i * 32 * RS + pl * 16 + rd1[ks]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + j * 32 * RS + ks * 24 + pl * 4);
+          for (int pl = 0; pl < 3; ++pl) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + j * 32 * RS + pl * 16 + rd1[ks]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -701,7 +706,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   dst[d] = pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx);
 }
 
-// bf16x3 layout: [tap][32-channel chunk][Npad][12 chunks][8 bf16]; chunk (g*3 + p) holds plane p (hi/mid/lo) of
+// bf16x3 layout: [tap][32-channel chunk][Npad][12 chunks][8 bf16]; chunk (p*4 + g) holds plane p (hi/mid/lo) of
 // channels 8g..8g+7 of the 32-channel chunk.  The three planes sum to the fp32 weight exactly.
 __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
                                         int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total) {
@@ -723,9 +728,9 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb & 0xFFFF0000u));
   const size_t row = ((size_t)(tap * kc32 + c_chunk) * npad + nn) * 96;      // 96 bf16 = 192 B per row
   const int g = kk >> 3, e = kk & 7;
-  dst[row + (g * 3 + 0) * 8 + e] = (unsigned short)(hb >> 16);
-  dst[row + (g * 3 + 1) * 8 + e] = (unsigned short)(mb >> 16);
-  dst[row + (g * 3 + 2) * 8 + e] = (unsigned short)(lb >> 16);
+  dst[row + (0 * 4 + g) * 8 + e] = (unsigned short)(hb >> 16);
+  dst[row + (1 * 4 + g) * 8 + e] = (unsigned short)(mb >> 16);
+  dst[row + (2 * 4 + g) * 8 + e] = (unsigned short)(lb >> 16);
 }
 
 __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
@@ -768,7 +773,7 @@ static int conv_mode() {
 
 template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
-  constexpr size_t pipe = MODE ? (size_t)((BM + BN <= 128) ? 2 : 1) * (BM + BN) * 52 * sizeof(float)
+  constexpr size_t pipe = MODE ? (size_t)((BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
                                : (size_t)2 * (BM + BN) * BK * sizeof(float);
   constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float) + (size_t)WGM * 32 * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
