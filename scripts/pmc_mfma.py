@@ -36,8 +36,8 @@ def main():
             a[k] += v
         a["_ns"] += dur.get(d, 0)
         a["_n"] += 1
-    print("| kernel | launches | wall ms (profiled) | eff. clock GHz | MFMA pipe util | fp32 MFMA TF/s implied | wait_any | wait_inst | active_inst | LDS conflict / LDS active |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | launches | wall ms (profiled) | eff. clock GHz | MFMA pipe util | executed MFMA TF/s | fp32-equivalent TF/s | wait_any | wait_inst | active_inst | LDS conflict / LDS active |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["_ns"]):
         if a["_ns"] < 2e5:
             continue
@@ -45,9 +45,13 @@ def main():
         clk = gui / a["_ns"] if a["_ns"] else 0.0
         util = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else 0.0
         wc = a.get("SQ_WAVE_CYCLES", 0.0) or 1.0
-        tf = util * 1024 * 64 * clk / 1e3           # 64 FLOP / clk / SIMD
+        # last template argument of conv_igemm_kernel: 1 = bf16 split operands (1024 FLOP/clk/SIMD, 6 MFMA FLOP per
+        # algorithmic FLOP), 0 = fp32 operands (64 FLOP/clk/SIMD)
+        split = k.rstrip(">").endswith(", 1")
+        tf = util * 1024 * (1024 if split else 64) * clk / 1e3
+        tf_eq = tf / 6.0 if split else tf
         ldsr = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"] if a.get("SQ_LDS_IDX_ACTIVE") else float("nan")
-        print(f"| `{k[:60]}` | {int(a['_n'])} | {a['_ns'] / 1e6:.2f} | {clk:.2f} | {100 * util:.1f} % | {tf:.1f} | "
+        print(f"| `{k[:60]}` | {int(a['_n'])} | {a['_ns'] / 1e6:.2f} | {clk:.2f} | {100 * util:.1f} % | {tf:.0f} | {tf_eq:.1f} | "
               f"{100 * a.get('SQ_WAIT_ANY', 0) / wc:.1f} % | {100 * a.get('SQ_WAIT_INST_ANY', 0) / wc:.1f} % | "
               f"{100 * a.get('SQ_ACTIVE_INST_ANY', 0) / wc:.1f} % | {ldsr:.3f} |")
 
