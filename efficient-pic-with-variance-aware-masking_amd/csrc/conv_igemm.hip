@@ -394,10 +394,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       b_loff[j] = in_tile ? row * RS + ((c & ~3) | ((c & 3) ^ ((row >> 2) & 3))) * 4 : -1;
     }
     const int u_Cin = __builtin_amdgcn_readfirstlane(P.Cin);
-    float4 ra[NA][2];
-    u32x4 rb[NBC];
+    // register stages: chunk c lives in stage c & 1 between its global loads and its LDS store.  Double-buffered
+    // (small) tiles use both stages, so a load has TWO compute phases to land — their phases are only 12-24 MFMAs long;
+    // single-buffered (wide) tiles use stage 0 only.
+    float4 ra0[NA][2], ra1[NA][2];
+    u32x4 rb0[NBC], rb1[NBC];
 
-    auto gload = [&]() {
+    auto gload = [&](float4 (&ra)[NA][2], u32x4 (&rb)[NBC]) {
       const int cc0 = c_kc * 32;
       if (cc0 < s_begin || cc0 >= s_end) {           // input segment changed (rare; see MODE 0)
         const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     };
     static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
     const int st1_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float4 (&ra)[NA][2], const u32x4 (&rb)[NBC]) {
       float* a = sA1 + buf * BM * RS;
       float* b = sB1 + buf * BN * RS;
 #pragma unroll
@@ -514,24 +517,35 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
       }
     };
     if constexpr (NBUF == 2) {
-      // one barrier per chunk: chunk ch+1 goes to the other buffer before chunk ch is computed
-      gload();
-      sstore(0);
-      if (n_chunks > 1) gload();
+      // one barrier per chunk; at the top of step ch: LDS[ch&1] = chunk ch, stage (ch+1)&1 = chunk ch+1 (requested two
+      // steps ago), stage ch&1 = chunk ch+2 (requested one step ago)
+      gload(ra0, rb0);
+      sstore(0, ra0, rb0);
+      if (n_chunks > 1) gload(ra1, rb1);
+      if (n_chunks > 2) gload(ra0, rb0);
       __syncthreads();
-      for (int ch = 0; ch < n_chunks; ++ch) {
-        if (ch + 1 < n_chunks) sstore((ch + 1) & 1);
-        if (ch + 2 < n_chunks) gload();
-        compute(ch & 1);
+      int ch = 0;
+      for (; ch + 1 < n_chunks; ch += 2) {
+        sstore(1, ra1, rb1);                          // chunk ch+1
+        if (ch + 3 < n_chunks) gload(ra1, rb1);       // chunk ch+3
+        compute(0);
+        __syncthreads();
+        if (ch + 2 < n_chunks) sstore(0, ra0, rb0);   // chunk ch+2
+        if (ch + 4 < n_chunks) gload(ra0, rb0);       // chunk ch+4
+        compute(1);
+        __syncthreads();
+      }
+      if (ch < n_chunks) {                            // odd chunk count: the last chunk sits in LDS[0]
+        compute(0);
         __syncthreads();
       }
     } else {
       // single LDS buffer (wide tiles): registers hold chunk ch+1 while chunk ch is computed
-      gload();
+      gload(ra0, rb0);
       for (int ch = 0; ch < n_chunks; ++ch) {
-        sstore(0);
+        sstore(0, ra0, rb0);
         __syncthreads();
-        if (ch + 1 < n_chunks) gload();
+        if (ch + 1 < n_chunks) gload(ra0, rb0);
         compute(0);
         __syncthreads();
       }
