@@ -72,12 +72,15 @@ def test_epoch(batches: Iterable[torch.Tensor], model, pr_list: Sequence[float],
     return [sum(v) / len(v) for v in bpp], [sum(v) / len(v) for v in psnr]
 
 
-def compress_with_ac(model, images: Iterable[torch.Tensor], pr_list: Sequence[float], rems: bool = False):
+def compress_with_ac(model, images: Iterable[torch.Tensor], pr_list: Sequence[float], rems: bool = False,
+                     with_msssim: bool = False):
     """training/step.py:259-358: real codec evaluation — compress + decompress every (unpadded) image at every
     quality; bpp = 8 * bytes / pixels of the ORIGINAL image, PSNR on the cropped reconstruction.
-    Returns (bpp, psnr, enc_seconds, dec_seconds) lists per quality."""
+    Returns (bpp, psnr, enc_seconds, dec_seconds) lists per quality, plus the MS-SSIM in dB
+    (-10 log10(1 - ms_ssim), step.py:323-324) as a fifth list when ``with_msssim``."""
     nq = len(pr_list)
     bpp, psnr, t_enc, t_dec = [[] for _ in range(nq)], [[] for _ in range(nq)], [[] for _ in range(nq)], [[] for _ in range(nq)]
+    mssim = [[] for _ in range(nq)]
     with torch.no_grad():
         for x in images:
             xp, unpad = pad_image(x)
@@ -94,9 +97,13 @@ def compress_with_ac(model, images: Iterable[torch.Tensor], pr_list: Sequence[fl
                 n_bytes = sum(len(s) for sl in enc["strings"][0] for s in sl) + sum(len(s) for s in enc["strings"][1])
                 bpp[j].append(8.0 * n_bytes / (x.shape[0] * x.shape[2] * x.shape[3]))
                 psnr[j].append(compute_psnr(x, x_hat))
+                if with_msssim:
+                    mssim[j].append(-10.0 * math.log10(max(1.0 - compute_msssim(x, x_hat), 1e-12)))
                 t_enc[j].append(t1 - t0)
                 t_dec[j].append(t2 - t1)
     avg = lambda rows: [sum(v) / len(v) for v in rows]
+    if with_msssim:
+        return avg(bpp), avg(psnr), avg(t_enc), avg(t_dec), avg(mssim)
     return avg(bpp), avg(psnr), avg(t_enc), avg(t_dec)
 
 
@@ -148,3 +155,43 @@ def write_image(x: torch.Tensor, filepath):
         x = x[0]
     a = (x.detach().clamp(0, 1).mul(255.0).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy())
     Image.fromarray(np.ascontiguousarray(a), mode="RGB").save(filepath)
+
+
+MS_SSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def compute_msssim(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0) -> float:
+    """utility/functions.py:176-177: ``ms_ssim(a, b, data_range=1.)`` of pytorch_msssim 0.2.1 — 11-tap Gaussian
+    (sigma 1.5), 5 scales, default weights, mean over images and channels — on the GPU (``vam_ssim_level``,
+    ``vam_avgpool2``).  NCHW fp32 CUDA tensors; the smaller side must exceed 160 pixels."""
+    from . import _lib as L
+    L.require_gpu()
+    if a.shape != b.shape or a.dim() != 4:
+        raise ValueError(f"expected two [B,C,H,W] tensors of one shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+    if min(a.shape[2:]) <= (11 - 1) * 2 ** 4:
+        raise ValueError("image too small for 5 scales with an 11-tap window (smaller side must exceed 160)")
+    lib = L.load()
+    x, y = a.detach().float().contiguous(), b.detach().float().contiguous()
+    B, C_, H, W = x.shape
+    planes = B * C_
+    coords = torch.arange(11, dtype=torch.float32) - 5
+    g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+    win = (g / g.sum()).to(x.device)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    vals = []
+    for lvl in range(5):
+        sums = torch.zeros((2, planes), dtype=torch.float64, device=x.device)
+        L.check(lib.vam_ssim_level(x.data_ptr(), y.data_ptr(), planes, H, W, win.data_ptr(), c1, c2, sums[0].data_ptr(),
+                                   sums[1].data_ptr(), ops.stream_ptr()), "vam_ssim_level")
+        mean = sums / float((H - 10) * (W - 10))
+        vals.append(torch.relu(mean[1] if lvl < 4 else mean[0]))
+        if lvl < 4:
+            ph, pw = H % 2, W % 2
+            Ho, Wo = (H + 2 * ph - 2) // 2 + 1, (W + 2 * pw - 2) // 2 + 1
+            nx = torch.empty((B, C_, Ho, Wo), dtype=torch.float32, device=x.device)
+            ny = torch.empty_like(nx)
+            L.check(lib.vam_avgpool2(x.data_ptr(), nx.data_ptr(), planes, H, W, ph, pw, ops.stream_ptr()), "vam_avgpool2")
+            L.check(lib.vam_avgpool2(y.data_ptr(), ny.data_ptr(), planes, H, W, ph, pw, ops.stream_ptr()), "vam_avgpool2")
+            x, y, H, W = nx, ny, Ho, Wo
+    w = torch.tensor(MS_SSIM_WEIGHTS, dtype=torch.float64, device=x.device).reshape(-1, 1)
+    return float(torch.prod(torch.stack(vals, 0) ** w, dim=0).mean())

@@ -219,6 +219,16 @@ int vam_memset_zero(void* ptr, size_t bytes, void* stream);
 /* sum((a-b)^2) accumulated in double into acc[0] (PSNR, utility/functions.py:172-174) */
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
 
+/* ------------------------------------------------------------------ MS-SSIM pieces (utility/functions.py:176-177) */
+/* One SSIM level over `planes` contiguous HxW planes (NCHW): 11-tap Gaussian window `win11` applied to x, y, x^2, y^2, xy
+ * at the (H-10)x(W-10) valid positions; ADDS the per-plane sums of the ssim map and of the cs map to ssim_sum / cs_sum
+ * (device doubles, one per plane; zero them first).  c1 = (0.01 L)^2, c2 = (0.03 L)^2. */
+int vam_ssim_level(const float* x, const float* y, int planes, int H, int W, const float* win11, float c1, float c2,
+                   double* ssim_sum, double* cs_sum, void* stream);
+/* F.avg_pool2d(kernel 2, stride 2, padding (pad_h, pad_w) in {0,1}, padded zeros counted): out is
+ * [planes][(H+2ph-2)/2+1][(W+2pw-2)/2+1]. */
+int vam_avgpool2(const float* x, float* out, int planes, int H, int W, int pad_h, int pad_w, void* stream);
+
 /* ------------------------------------------------------------------ REM fine-tune backward (configs[4]) */
 /* Weight (and bias) gradient of a stride-1, pad k/2 convolution (autograd's conv backward-weight for
  * layers/rem.py:40-49):  dw[n][c_off + c][ty][tx] = sum_p dy[p][n] * x[pix(p)+(ty-k/2, tx-k/2)][c]  in OIHW with

@@ -138,3 +138,21 @@ def test_eval_drivers(codec):
     assert abs(e_psnr[1] - O.psnr(xp.cpu(), out["x_hat"].cpu())) < 1e-4
     assert abs(e_bpp[1] - O.bpp({k: v.cpu() for k, v in out["likelihoods"].items()}, 64 * 128)) < 1e-6 * e_bpp[1]
     print("real codec: bpp", bpp, "psnr", psnr, "enc s", te, "dec s", td)
+
+
+def test_msssim_matches_cpu_restatement():
+    """compute_msssim (HIP: 11x11 Gaussian SSIM levels + 2x2 pooling) against the CPU restatement of pytorch_msssim's
+    published algorithm (oracle/msssim_oracle.py; package absent offline, so unpinned).  Tolerance 2e-6 absolute
+    (fp32 window sums vs float64)."""
+    import msssim_oracle as MO
+    from vampic.evaluate import compute_msssim
+    for seed, shp, noise in ((1, (2, 3, 192, 256), 0.05), (2, (1, 3, 161, 203), 0.2), (3, (1, 1, 512, 768), 0.01)):
+        a = synth.uniform(shp, seed)
+        b = (a + noise * (synth.uniform(shp, seed + 50) - 0.5)).clamp(0, 1)
+        want = MO.ms_ssim(a, b, 1.0)
+        got = compute_msssim(a.cuda(), b.cuda())
+        assert abs(got - want) <= 2e-6, (shp, got, want)
+        assert 0.0 < got < 1.0
+    assert abs(compute_msssim(a.cuda(), a.cuda()) - 1.0) <= 1e-6
+    with pytest.raises(ValueError):
+        compute_msssim(torch.zeros(1, 3, 128, 300).cuda(), torch.zeros(1, 3, 128, 300).cuda())
