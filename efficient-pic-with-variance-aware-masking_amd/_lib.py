@@ -17,7 +17,7 @@ VAM_MAX_GROUP = 8
 # enum vam_act
 ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQRT, ACT_SQRT = range(8)
 # enum vam_conv_flags
-CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW = 1, 2, 4
+CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW, CONV_IN_BF3, CONV_OUT_BF3 = 1, 2, 4, 8, 16
 # enum vam_pack_mode
 PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD = range(5)
 # enum vam_family

@@ -82,7 +82,11 @@ constexpr int PK = 16;  // packing granularity of the weight buffer along K
 //         (scratch/probe/bf16x3.hip: rms 1.06e-6 vs 1.22e-6 at K = 4800).  The bf16 pipe runs 16x the fp32 MFMA rate,
 //         so six products cost 6/16 of the fp32 matrix time.  Weights are split once at pack time, activations when
 //         they are staged into LDS.
-template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
+// AIN (MODE 1 only): 0 = fp32 NHWC input segments, split into bf16x3 while staging; 1 = input already stored as bf16x3
+// planes ("P3": [pixel][8-channel group][plane 3][8 bf16], 48 B per group) by the producing launch's epilogue
+// (VAM_CONV_OUT_BF3) — the staging is then a pure copy, like the weights'.  Inside conv stacks every intermediate is
+// consumed by exactly one convolution, which otherwise re-splits each element once per tap and per N tile.
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const GroupArgs args) {
   constexpr int NT = WGM * WGN * 64;         // threads per block
   constexpr int LDS_LD = BK;                 // floats per LDS row: no padding, the 16-byte chunks of a row are
@@ -397,10 +401,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     // register stages: chunk c lives in stage c & 1 between its global loads and its LDS store.  Double-buffered
     // (small) tiles use both stages, so a load has TWO compute phases to land — their phases are only 12-24 MFMAs long;
     // single-buffered (wide) tiles use stage 0 only.
-    float4 ra0[NA][2], ra1[NA][2];
+    constexpr int NAR = AIN ? 3 : 2;                 // 16-byte registers per staged A unit (P3: three planes; fp32: 8 floats)
+    u32x4 ra0[NA][NAR], ra1[NA][NAR];
     u32x4 rb0[NBC], rb1[NBC];
 
-    auto gload = [&](float4 (&ra)[NA][2], u32x4 (&rb)[NBC]) {
+    auto gload = [&](u32x4 (&ra)[NA][NAR], u32x4 (&rb)[NBC]) {
       const int cc0 = c_kc * 32;
       if (cc0 < s_begin || cc0 >= s_end) {           // input segment changed (rare; see MODE 0)
         const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
@@ -409,21 +414,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
         const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
         s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);
         s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));
-        s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * 4;
+        s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * (AIN ? 48 : 4);   // bytes per pixel (P3: ld counts 8-channel groups)
       }
       const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
       const int tap_pix = c_ty * u_W + c_tx;
-      const int col4 = (cc0 - s_begin + ld_col) * 4;
+      // byte offset of this thread's 8 channels inside a pixel: 32 B of fp32, or one 48-byte P3 group
+      const int col4 = AIN ? ((cc0 - s_begin + ld_col) >> 3) * 48 : (cc0 - s_begin + ld_col) * 4;
       const bool ch_ok = cc0 + ld_col < u_Cin;       // the last chunk of a 16-mod-32 channel count is half empty
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
         const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0);
-        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u), 0, 0);
-        ra[i][0] = make_float4(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w));
-        ra[i][1] = make_float4(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w));
+#pragma unroll
+        for (int q = 0; q < NAR; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * q), 0, 0);
       }
       // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
       const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 192u;
@@ -442,13 +446,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     };
     static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
     const int st1_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
-    auto sstore = [&](int buf, const float4 (&ra)[NA][2], const u32x4 (&rb)[NBC]) {
+    auto sstore = [&](int buf, const u32x4 (&ra)[NA][NAR], const u32x4 (&rb)[NBC]) {
       float* a = sA1 + buf * BM * RS;
       float* b = sB1 + buf * BN * RS;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         if (A_FULL || ld_row + i * RPP < BM) {
-          float x[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+          if constexpr (AIN) {                       // planes arrive ready-made: three straight copies
+            float* dst = a + (ld_row + i * RPP) * RS + st1_col;
+            *reinterpret_cast<u32x4*>(dst) = ra[i][0];
+            *reinterpret_cast<u32x4*>(dst + 16) = ra[i][1];
+            *reinterpret_cast<u32x4*>(dst + 32) = ra[i][NAR - 1];
+            continue;
+          }
+          float x[8] = {__uint_as_float(ra[i][0].x), __uint_as_float(ra[i][0].y), __uint_as_float(ra[i][0].z), __uint_as_float(ra[i][0].w),
+                        __uint_as_float(ra[i][1].x), __uint_as_float(ra[i][1].y), __uint_as_float(ra[i][1].z), __uint_as_float(ra[i][1].w)};
           if (sq) {                                  // GDN pools x^2 (block-uniform branch)
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = x[e] * x[e];
@@ -565,6 +577,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const bool dense = !ps2 && !nchw && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
                      P.Hf == P.Ho && P.Wf == P.Wo;
   const bool vec_ok = !nchw && (!ps2 || (P.Cq & 3) == 0);
+  const bool out_p3 = (P.flags & VAM_CONV_OUT_BF3) != 0;     // host guarantees: split mode, vec_ok, no PS2
   const int Cc = ps2 ? P.Cq : P.N;
   const size_t HfWf = (size_t)P.Hf * P.Wf;
 #pragma unroll
@@ -635,7 +648,24 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
           const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
           v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
         }
-        *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+        if (out_p3) {
+          // bf16x3 planes for the consuming convolution: [pixel][8-channel group][plane][8 bf16]; this lane owns
+          // channels cch..cch+3 = 8 bytes of each plane
+          unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            hb[k] = __float_as_uint(v[k]);
+            const float r1 = v[k] - __uint_as_float(hb[k] & 0xFFFF0000u);
+            mb[k] = __float_as_uint(r1);
+            lb[k] = __float_as_uint(r1 - __uint_as_float(mb[k] & 0xFFFF0000u));
+          }
+          char* o3 = reinterpret_cast<char*>(P.out) + (opix * P.ldo + (size_t)(cch >> 3)) * 48 + (cch & 7) * 2;
+          *reinterpret_cast<uint2*>(o3) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+          *reinterpret_cast<uint2*>(o3 + 16) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+          *reinterpret_cast<uint2*>(o3 + 32) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+        } else {
+          *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       } else {
         // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
         for (int k = 0; k < 4; ++k) {
@@ -785,7 +815,7 @@ static int conv_mode() {
   return g_mode;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int MODE>
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   constexpr size_t pipe = MODE ? (size_t)((BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
                                : (size_t)2 * (BM + BN) * BK * sizeof(float);
@@ -793,7 +823,7 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
@@ -801,7 +831,7 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   int per_xcd = 0;
   for (int i = 0; i < ga.nprob; ++i) per_xcd += (ga.tile_start[i + 1] - ga.tile_start[i] + 7) / 8;
   (void)total_tiles;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
   return check_launch("conv_igemm_kernel");
 }
 
@@ -877,6 +907,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   VAM_REQUIRE(probs && nprob >= 1 && nprob <= VAM_MAX_GROUP, "vam_conv_group: 1..%d problems", VAM_MAX_GROUP);
   GroupArgs ga;
   ga.nprob = nprob;
+  bool in_p3 = false;
   int bk = 0;
   long max_p = 0;
   int max_n = 0;
@@ -889,10 +920,21 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     VAM_REQUIRE(c.kh >= 1 && c.kh <= 5 && c.kw >= 1 && c.kw <= 5 && (c.stride == 1 || c.stride == 2), "conv[%d]: kernel %dx%d stride %d", i, c.kh, c.kw, c.stride);
     VAM_REQUIRE(c.wpack && c.out, "conv[%d]: null weights/output", i);
     int cin = 0;
+    const bool p3_in = (c.flags & VAM_CONV_IN_BF3) != 0, p3_out = (c.flags & VAM_CONV_OUT_BF3) != 0;
+    if (i == 0) in_p3 = p3_in;
+    VAM_REQUIRE(p3_in == in_p3, "conv group mixes fp32 and bf16x3-plane inputs");
+    if (p3_in || p3_out) VAM_REQUIRE(conv_mode() == 1, "conv[%d]: bf16x3-plane tensors need the split-operand mode", i);
+    if (p3_in) VAM_REQUIRE(!(c.flags & VAM_CONV_SQUARE_IN), "conv[%d]: SQUARE_IN needs fp32 input", i);
+    if (p3_out) VAM_REQUIRE(!(c.flags & (VAM_CONV_PS2 | VAM_CONV_OUT_NCHW)) && c.N % 8 == 0 && c.ldo * 8 >= c.N, "conv[%d]: bf16x3-plane output needs plain NHWC placement, N %% 8 == 0 and ldo (groups) >= N/8", i);
     for (int s = 0; s < VAM_MAX_SEG; ++s) {
       if (s < c.n_seg) {
+        if (p3_in) {      // ld counts 8-channel groups (48 bytes each)
+          VAM_REQUIRE(c.seg[s].ptr && c.seg[s].C > 0 && c.seg[s].C % 8 == 0 && c.seg[s].ld * 8 >= c.seg[s].C, "conv[%d]: bf16x3 segment %d invalid", i, s);
+          VAM_REQUIRE((((uintptr_t)c.seg[s].ptr) % 16) == 0, "conv[%d]: segment %d not 16-byte aligned", i, s);
+        } else {
         VAM_REQUIRE(c.seg[s].ptr && c.seg[s].C > 0 && c.seg[s].ld >= c.seg[s].C, "conv[%d]: segment %d invalid", i, s);
         VAM_REQUIRE((c.seg[s].ld % 4) == 0 && (((uintptr_t)c.seg[s].ptr) % 16) == 0, "conv[%d]: segment %d not 16-byte aligned", i, s);
+        }
         cin += c.seg[s].C;
         p.seg_ptr[s] = c.seg[s].ptr;
         p.seg_ld[s] = c.seg[s].ld;
@@ -907,7 +949,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     int pbk = mode1 ? 32 : bk_for(cin);
     VAM_REQUIRE(cin % 16 == 0, "conv[%d]: Cin %d not a multiple of 16", i, cin);
     for (int sgi = 0; sgi < c.n_seg; ++sgi)
-      VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * 4.0 < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
+      VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * (p3_in ? 48.0 : 4.0) < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
     VAM_REQUIRE((double)vam_conv_wpack_floats(c.kh, c.kw, cin, c.N) * 4.0 < 2147000000.0, "conv[%d]: packed weights larger than 2 GiB", i);
     for (int s = 0; s + 1 < c.n_seg; ++s)
       VAM_REQUIRE(p.seg_end[s] % pbk == 0, "conv[%d]: segment boundary %d not a multiple of BK=%d", i, p.seg_end[s], pbk);
@@ -925,13 +967,13 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       const bool vec = !(c.flags & VAM_CONV_OUT_NCHW) && (!(c.flags & VAM_CONV_PS2) || (c.Cq % 4) == 0);
       auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
       if (vec) {
-        VAM_REQUIRE(c.ldo % 4 == 0 && al(c.out) && al(c.bias), "conv[%d]: output/bias not 16-byte aligned", i);
+        VAM_REQUIRE((p3_out || c.ldo % 4 == 0) && al(c.out) && al(c.bias), "conv[%d]: output/bias not 16-byte aligned", i);
         VAM_REQUIRE((!c.pre.ptr || (c.pre.ld % 4 == 0 && al(c.pre.ptr))) && (!c.mul.ptr || (c.mul.ld % 4 == 0 && al(c.mul.ptr))) &&
                     (!c.post.ptr || (c.post.ld % 4 == 0 && al(c.post.ptr))) && (!c.post2.ptr || (c.post2.ld % 4 == 0 && al(c.post2.ptr))),
                     "conv[%d]: epilogue operand not 16-byte aligned", i);
       }
     }
-    if (!(c.flags & VAM_CONV_OUT_NCHW)) VAM_REQUIRE(c.ldo >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N), "conv[%d]: ldo %d < channels", i, c.ldo);
+    if (!(c.flags & VAM_CONV_OUT_NCHW) && !p3_out) VAM_REQUIRE(c.ldo >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N), "conv[%d]: ldo %d < channels", i, c.ldo);
     p.n_seg = c.n_seg;
     p.H = c.H; p.W = c.W; p.HW = c.H * c.W;
     p.kh = c.kh; p.kw = c.kw; p.stride = c.stride; p.pad_y = c.pad_y; p.pad_x = c.pad_x;
@@ -1026,7 +1068,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
   if (conv_mode() == 1) {
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
-    if (bm == BM_ && best_bn == BN_) return launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1>(ga, total, s);
+    if (bm == BM_ && best_bn == BN_) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1>(ga, total, s) \
+                                                  : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 0>(ga, total, s);
     VAM_CFG1(128, 32, 4, 1) VAM_CFG1(128, 64, 2, 2) VAM_CFG1(128, 96, 4, 1) VAM_CFG1(128, 128, 2, 2) VAM_CFG1(128, 192, 2, 2)
     VAM_CFG1(64, 32, 2, 1) VAM_CFG1(64, 64, 2, 2) VAM_CFG1(64, 128, 2, 2) VAM_CFG1(64, 192, 2, 2)
 #undef VAM_CFG1

@@ -46,6 +46,12 @@ class Plan:
         self.keep.append(v.buf)
         return v
 
+    def buf3(self, B, H, W, C) -> "ops.View3":
+        """bf16x3-plane buffer for a tensor whose only consumer is another convolution."""
+        v = ops.new_view3(B, H, W, C, self.device)
+        self.keep.append(v.buf)
+        return v
+
     # ---- recorded launches
     def conv(self, problems: Sequence[L.VamConv]):
         lib = L.load()
@@ -195,6 +201,11 @@ def _out_extent(m, v: View):
     return (v.H + 2 * (k // 2) - k) // s + 1, (v.W + 2 * (k // 2) - k) // s + 1, m.out_channels
 
 
+# Plane tensors pay off where the consumer's tiles are small (latent-resolution stacks: the split is a sizeable share
+# of their per-chunk work); on the big feature maps the 8-byte plane stores and 1.5x bytes cost more than they save.
+P3_MAX_PIXELS = 16384
+
+
 def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[Sequence[View]],
                  outs: Sequence[Optional[View]], final: Optional[Sequence[dict]] = None) -> List[View]:
     """Run K structurally identical conv stacks in lockstep: layer d of every stack is one
@@ -206,6 +217,9 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
     assert all(len(l) == depth for l in lay)
     cur: List[Sequence[View]] = [list(i) for i in inputs]
     res: List[View] = []
+    # intermediates of a stack are read by the next layer only: with the split-operand kernel they are written as
+    # bf16x3 planes by the producer (one split per element) instead of being re-split per tap and N tile downstream
+    p3 = ops.split_mode()
     for d in range(depth):
         probs = []
         nxt = []
@@ -216,6 +230,8 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
             last = d == depth - 1
             if last and outs[k] is not None:
                 o = outs[k]
+            elif p3 and not last and Co % 8 == 0 and m.packed().ps2_cq == 0 and v0.B * Ho * Wo <= P3_MAX_PIXELS:
+                o = plan.buf3(v0.B, Ho, Wo, Co)
             else:
                 o = plan.buf(v0.B, Ho, Wo, Co)
             kw = {}

@@ -47,6 +47,50 @@ class View:
         return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
 
 
+@dataclass
+class View3:
+    """A channel window of a bf16x3-plane ("P3") tensor: [B, H, W, groups][plane 3][8 bf16], 48 bytes per 8-channel
+    group (stored in an fp32 tensor of 12 floats per group).  Written by a conv launch with VAM_CONV_OUT_BF3 and read
+    only by convolutions (VAM_CONV_IN_BF3): the exact hi/mid/lo split of each fp32 value, made once by the producer."""
+    buf: torch.Tensor   # [B, H, W, 12 * groups] fp32 storage
+    g0: int
+    C: int
+
+    @property
+    def B(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3] // 12      # groups per pixel
+    @property
+    def ptr(self): return self.buf.data_ptr() + 48 * self.g0
+    @property
+    def n_pix(self): return self.B * self.H * self.W
+
+    def window(self, c0: int, C_: int) -> "View3":
+        assert c0 % 8 == 0 and C_ % 8 == 0 and 0 <= c0 and c0 + C_ <= self.C
+        return View3(self.buf, self.g0 + c0 // 8, C_)
+
+    def to_float(self) -> torch.Tensor:
+        """Decode to a [B,H,W,C] fp32 tensor (hi + mid + lo; test / debug helper)."""
+        B, H, W = self.B, self.H, self.W
+        raw = self.buf.view(torch.int16).view(B, H, W, self.ld, 3, 8)[..., self.g0:self.g0 + self.C // 8, :, :]
+        planes = (raw.to(torch.int32) << 16).view(torch.float32)
+        return (planes[..., 0, :] + planes[..., 1, :] + planes[..., 2, :]).reshape(B, H, W, self.C)
+
+
+def new_view3(B: int, H: int, W: int, C_: int, device="cuda") -> View3:
+    assert C_ % 8 == 0
+    return View3(torch.zeros((B, H, W, (C_ // 8) * 12), dtype=torch.float32, device=device), 0, C_)
+
+
+def split_mode() -> bool:
+    """True when the convolution kernel runs on split bf16x3 operands (the default)."""
+    return L.load().vam_conv_get_mode() == 1
+
+
 def new_view(B: int, H: int, W: int, C_: int, device="cuda", zero: bool = False) -> View:
     f = torch.zeros if zero else torch.empty
     return View(f((B, H, W, C_), dtype=torch.float32, device=device), 0, C_)
@@ -199,6 +243,13 @@ def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT
     """Describe one problem.  ``inputs`` are concatenated along channels (virtually)."""
     c = L.VamConv()
     assert 1 <= len(inputs) <= L.VAM_MAX_SEG
+    in3 = isinstance(inputs[0], View3)
+    assert all(isinstance(v, View3) == in3 for v in inputs), "a conv problem reads either fp32 or bf16x3-plane segments"
+    if in3:
+        flags |= L.CONV_IN_BF3
+    if isinstance(out, View3):
+        assert out_nchw is None
+        flags |= L.CONV_OUT_BF3
     B, H, W = inputs[0].B, inputs[0].H, inputs[0].W
     cin = 0
     for i, v in enumerate(inputs):

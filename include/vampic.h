@@ -56,7 +56,12 @@ enum vam_conv_flags {
   VAM_CONV_SQUARE_IN = 1,   /* operand is x*x (GDN norm pool, gdn.py:68)                 */
   VAM_CONV_PS2 = 2,         /* phase-major output channels scattered like PixelShuffle(2):
                                n = phase*Cq + c -> pixel (2y+phase/2, 2x+phase%2), chan c  */
-  VAM_CONV_OUT_NCHW = 4     /* store the result NCHW (model edge, x_hat)                  */
+  VAM_CONV_OUT_NCHW = 4,    /* store the result NCHW (model edge, x_hat)                  */
+  VAM_CONV_IN_BF3 = 8,      /* every input segment holds bf16x3 planes ("P3": [pixel][8-channel group][plane 3][8 bf16],
+                               48 bytes per group; seg.ld counts GROUPS per pixel, seg.C channels) written by a launch
+                               with VAM_CONV_OUT_BF3 — the split-operand kernel then stages them by plain copies     */
+  VAM_CONV_OUT_BF3 = 16     /* write the result as P3 planes (ldo counts groups per pixel) instead of fp32 NHWC; for
+                               tensors whose only consumer is another convolution (inside conv stacks)               */
 };
 
 #define VAM_MAX_SEG 4

@@ -258,3 +258,32 @@ def test_fp32_matrix_pipe_mode_in_a_child_process():
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_bf16x3_plane_tensors_are_transparent():
+    """Inside conv stacks the producer writes its output as bf16x3 planes (VAM_CONV_OUT_BF3) and the consumer stages them
+    by plain copies (VAM_CONV_IN_BF3).  The split is exact, so (a) decoding the planes returns the fp32 output bit for
+    bit and (b) a convolution fed with planes returns exactly what it returns on the fp32 tensor."""
+    if not ops.split_mode():
+        pytest.skip("bf16x3-plane tensors exist only in the split-operand mode")
+    B, H, W = 2, 16, 24
+    m1, m2 = Ly.Conv2d(96, 176, 3, 1).cuda(), Ly.Conv2d(176, 64, 3, 1).cuda()
+    _fill(m1, 41), _fill(m2, 42)
+    x = ops.from_nchw(_rand((B, 96, H, W), 43).cuda())
+    mid32, mid3 = ops.new_view(B, H, W, 176), ops.new_view3(B, H, W, 176)
+    ops.conv_group([ops.conv_problem(m1.packed(), [x], mid32, L.ACT_GELU)])
+    ops.conv_group([ops.conv_problem(m1.packed(), [x], mid3, L.ACT_GELU)])
+    assert torch.equal(mid3.to_float(), mid32.buf)                                     # (a)
+    o32, o3 = ops.new_view(B, H, W, 64), ops.new_view(B, H, W, 64)
+    ops.conv_group([ops.conv_problem(m2.packed(), [mid32], o32)])
+    ops.conv_group([ops.conv_problem(m2.packed(), [mid3], o3)])
+    assert torch.equal(o3.buf, o32.buf)                                                # (b)
+    # channel windows of a plane tensor, and a stride-2 consumer
+    m3 = Ly.Conv2d(64, 32, 3, 2).cuda()
+    _fill(m3, 44)
+    q32, q3 = ops.new_view(B, H // 2, W // 2, 32), ops.new_view(B, H // 2, W // 2, 32)
+    ops.conv_group([ops.conv_problem(m3.packed(), [mid32.window(112, 64)], q32)])
+    ops.conv_group([ops.conv_problem(m3.packed(), [mid3.window(112, 64)], q3)])
+    assert torch.equal(q3.buf, q32.buf)
+    with pytest.raises(Exception):                                                      # formats do not mix within a problem
+        ops.conv_problem(m2.packed(), [mid3.window(0, 88), mid32.window(88, 88)], o3)
