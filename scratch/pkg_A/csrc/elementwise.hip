@@ -1,0 +1,443 @@
+// HBM-bound element-wise kernels of the hot path: model-edge layout changes, the fused
+// Gaussian-conditional slice tail, build_indexes, the factorised-prior likelihood for z,
+// and two tiny helpers.  All are coalesced 16-byte-per-lane streams over NHWC channel
+// windows (pixel stride `ld`), grid-stride with <= 2048 blocks.
+//
+// This file is compiled with -ffp-contract=off: the reference evaluates these chains as
+// separate fp32 ops (entropy_models.py:140-149,620-652) and a contracted fma would change
+// bits.
+#include "common.h"
+
+namespace vam {
+
+__device__ __forceinline__ float phi_c(float t) {
+  // entropy_models.py:573-576: 0.5 * erfc(-(2**-0.5) * t)
+  return 0.5f * erfcf(-0.70710678118654752440f * t);
+}
+
+__device__ __forceinline__ float gauss_lik(float absv, float sigma) {
+  float s = fmaxf(sigma, 0.11f);                 // LowerBound(0.11), entropy_models.py:628
+  float upper = phi_c((0.5f - absv) / s);
+  float lower = phi_c((-0.5f - absv) / s);
+  return fmaxf(upper - lower, 1e-9f);            // likelihood_lower_bound, :650
+}
+
+// wave-aggregated atomic accumulation of a per-lane double into acc[item]
+__device__ __forceinline__ void wave_accumulate(double v, int item, double* acc) {
+  int first = __builtin_amdgcn_readfirstlane(item);
+  if (__all(item == first)) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc + first, v);
+  } else {
+    atomicAdd(acc + item, v);
+  }
+}
+
+// ------------------------------------------------------------------ layout
+__global__ void s2d_input_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W) {
+  // out[b, Y, X, (py*2+px)*3 + c] = x[b, c, 2Y+py, 2X+px]; channels 12..15 = 0
+  const int H2 = H / 2, W2 = W / 2;
+  long total = (long)B * H2 * W2 * 4;  // one float4 (= 4 channels) per thread
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int q = (int)(i & 3);
+    long pix = i >> 2;
+    int X = (int)(pix % W2);
+    long r = pix / W2;
+    int Y = (int)(r % H2);
+    int b = (int)(r / H2);
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int ch = q * 4 + k;
+      float val = 0.f;
+      if (ch < 12) {
+        int ph = ch / 3, c = ch - ph * 3;
+        int py = ph >> 1, px = ph & 1;
+        val = x[(((long)b * 3 + c) * H + 2 * Y + py) * W + 2 * X + px];
+      }
+      v[k] = val;
+    }
+    *reinterpret_cast<float4*>(out + pix * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW,
+                                    int ld) {
+  // tile transpose through LDS: 32 pixels x 32 channels
+  __shared__ float tile[32][33];
+  int b = blockIdx.z;
+  int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k, p = p0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? src[((long)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int p = p0 + k, c = c0 + tx;
+    if (p < HW && c < C) dst[((long)b * HW + p) * ld + c] = tile[tx][k];
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int B, int C,
+                                    int HW) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.z;
+  int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    int p = p0 + k, c = c0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? src[((long)b * HW + p) * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k, p = p0 + tx;
+    if (p < HW && c < C) dst[((long)b * C + c) * HW + p] = tile[tx][k];
+  }
+}
+
+// ------------------------------------------------------------------ Gaussian slice tail
+struct TailArgs {
+  const float *y, *y2, *mu, *sigma, *mask;
+  float *yhat, *lik;
+  int32_t* sym;
+  double* log2sum;
+  int ld_y, ld_y2, ld_mu, ld_sigma, ld_mask, ld_yhat, ld_lik, ld_sym;
+  int pix_per_item, C4;  // C4 = C/4
+  long n_vec;            // n_pix * C4
+};
+
+__global__ void gauss_tail_kernel(const TailArgs a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / a.C4;
+    int c = (int)(i - p * a.C4) * 4;
+    float4 y = *reinterpret_cast<const float4*>(a.y + p * a.ld_y + c);
+    if (a.y2) {
+      float4 y2 = *reinterpret_cast<const float4*>(a.y2 + p * a.ld_y2 + c);
+      y.x -= y2.x; y.y -= y2.y; y.z -= y2.z; y.w -= y2.w;            // pic.py:583-584
+    }
+    float4 mu = *reinterpret_cast<const float4*>(a.mu + p * a.ld_mu + c);
+    float4 sg = *reinterpret_cast<const float4*>(a.sigma + p * a.ld_sigma + c);
+    float yv[4] = {y.x, y.y, y.z, y.w}, mv[4] = {mu.x, mu.y, mu.z, mu.w}, sv[4] = {sg.x, sg.y, sg.z, sg.w};
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.mask) {
+      float4 m = *reinterpret_cast<const float4*>(a.mask + p * a.ld_mask + c);
+      mk[0] = m.x; mk[1] = m.y; mk[2] = m.z; mk[3] = m.w;
+    }
+    float yh[4], lk[4];
+    int sy[4];
+    double lsum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = yv[k] - mv[k];
+      float q = rintf(d);                         // torch.round = half-to-even
+      float absv, s;
+      if (a.mask) {
+        // pic.py:625-629: lik on round((r-mu)*m) with scale sigma*m ; yhat = round(r-mu)*m + mu
+        float in = d * mk[k];
+        float rq = rintf(in);
+        absv = fabsf(rq);
+        s = sv[k] * mk[k];
+        yh[k] = q * mk[k] + mv[k];
+        sy[k] = (int)rq;
+      } else {
+        // pic.py:545-546 + entropy_models.py:140-149,623-630: |(round(y-mu)+mu) - mu|
+        float o = q + mv[k];
+        absv = fabsf(o - mv[k]);
+        s = sv[k];
+        yh[k] = o;
+        sy[k] = (int)q;
+      }
+      lk[k] = gauss_lik(absv, s);
+      lsum += log2((double)lk[k]);
+    }
+    if (a.yhat) *reinterpret_cast<float4*>(a.yhat + p * a.ld_yhat + c) = make_float4(yh[0], yh[1], yh[2], yh[3]);
+    if (a.lik) *reinterpret_cast<float4*>(a.lik + p * a.ld_lik + c) = make_float4(lk[0], lk[1], lk[2], lk[3]);
+    if (a.sym) *reinterpret_cast<int4*>(a.sym + p * a.ld_sym + c) = make_int4(sy[0], sy[1], sy[2], sy[3]);
+    if (a.log2sum) wave_accumulate(lsum, (int)(p / a.pix_per_item), a.log2sum);
+  }
+}
+
+// ------------------------------------------------------------------ build_indexes
+__global__ void build_indexes_kernel(const float* __restrict__ sigma, int ld_sigma, const float* __restrict__ mask,
+                                     int ld_mask, const float* __restrict__ table, int n_table,
+                                     int32_t* __restrict__ idx, int ld_idx, long n_vec, int C4) {
+  __shared__ float tbl[256];
+  for (int i = threadIdx.x; i < n_table; i += blockDim.x) tbl[i] = table[i];
+  __syncthreads();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    float4 sg = *reinterpret_cast<const float4*>(sigma + p * ld_sigma + c);
+    float s[4] = {sg.x, sg.y, sg.z, sg.w};
+    if (mask) {
+      float4 m = *reinterpret_cast<const float4*>(mask + p * ld_mask + c);
+      s[0] *= m.x; s[1] *= m.y; s[2] *= m.z; s[3] *= m.w;
+    }
+    int r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = fmaxf(s[k], 0.11f);
+      int cnt = 0;
+      for (int t = 0; t < n_table - 1; ++t) cnt += (v <= tbl[t]) ? 1 : 0;   // entropy_models.py:657-658
+      r[k] = n_table - 1 - cnt;
+    }
+    *reinterpret_cast<int4*>(idx + p * ld_idx + c) = make_int4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ------------------------------------------------------------------ factorised prior (z)
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// params per tensor, channel-major as in the state_dict:
+//  m0[C*3] b0[C*3] f0[C*3] | m1[C*9] b1[C*3] f1[C*3] | m2.. | m3.. | m4[C*3] b4[C] | quantiles[C*3]
+__device__ __forceinline__ float eb_logits(const float* sp /*61 preprocessed floats*/, float x) {
+  float l[3], t[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = sp[k] * x + sp[3 + k];
+    l[k] = v + sp[6 + k] * tanhf(v);
+  }
+  const float* q = sp + 9;
+#pragma unroll
+  for (int layer = 0; layer < 3; ++layer) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = q[k * 3 + 0] * l[0];
+      v = v + q[k * 3 + 1] * l[1];
+      v = v + q[k * 3 + 2] * l[2];
+      v = v + q[9 + k];
+      t[k] = v + q[12 + k] * tanhf(v);
+    }
+    l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
+    q += 15;
+  }
+  float v = q[0] * l[0];
+  v = v + q[1] * l[1];
+  v = v + q[2] * l[2];
+  return v + q[3];
+}
+
+__global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ params, int C,
+                                  float* __restrict__ zhat, int ld_zhat, float* __restrict__ lik, int ld_lik,
+                                  int32_t* __restrict__ sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
+                                  const float* __restrict__ noise, int ld_noise) {
+  // one thread per channel (blockDim.x >= C), pixels strided over blockIdx / y
+  extern __shared__ float sh[];  // C * 62 floats of preprocessed params
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float* sp = sh + c * 62;
+    const float* m0 = params;
+    const float* b0 = m0 + C * 3;
+    const float* f0 = b0 + C * 3;
+    for (int k = 0; k < 3; ++k) {
+      sp[k] = softplusf(m0[c * 3 + k]);
+      sp[3 + k] = b0[c * 3 + k];
+      sp[6 + k] = tanhf(f0[c * 3 + k]);
+    }
+    const float* base = f0 + C * 3;
+    for (int layer = 0; layer < 3; ++layer) {
+      const float* m = base;
+      const float* b = m + C * 9;
+      const float* f = b + C * 3;
+      float* o = sp + 9 + layer * 15;
+      for (int k = 0; k < 9; ++k) o[k] = softplusf(m[c * 9 + k]);
+      for (int k = 0; k < 3; ++k) { o[9 + k] = b[c * 3 + k]; o[12 + k] = tanhf(f[c * 3 + k]); }
+      base = f + C * 3;
+    }
+    const float* m4 = base;
+    const float* b4 = m4 + C * 3;
+    const float* qn = b4 + C;
+    float* o = sp + 54;
+    for (int k = 0; k < 3; ++k) o[k] = softplusf(m4[c * 3 + k]);
+    o[3] = b4[c];
+    sp[58] = qn[c * 3 + 1];  // median (entropy_models.py:354-356)
+  }
+  __syncthreads();
+  int c = threadIdx.x;
+  if (c >= C) return;
+  const float* sp = sh + c * 62;
+  const float med = sp[58];
+  for (long p = blockIdx.x; p < n_pix; p += gridDim.x) {
+    float v = z[p * ld_z + c];
+    const float qz = rintf(v - med);
+    float o = qz + med;                           // quantize "dequantize" with medians
+    if (sym) sym[p * ld_sym + c] = (int)qz;       // quantize "symbols" (entropy_models.py:151-153)
+    // training: the likelihood is evaluated at z + U(-.5,.5) (quantize "noise", entropy_models.py:132-138,471-473)
+    const float at = noise ? v + noise[p * ld_noise + c] : o;
+    float lower = eb_logits(sp, at - 0.5f);
+    float upper = eb_logits(sp, at + 0.5f);
+    float sum = lower + upper;
+    float sign = sum > 0.f ? -1.f : (sum < 0.f ? 1.f : 0.f);   // -sign(lower+upper)
+    float su = 1.0f / (1.0f + expf(-(sign * upper)));
+    float sl = 1.0f / (1.0f + expf(-(sign * lower)));
+    float lk = fmaxf(fabsf(su - sl), 1e-9f);
+    if (zhat) zhat[p * ld_zhat + c] = o;
+    if (lik) lik[p * ld_lik + c] = lk;
+    if (log2sum) atomicAdd(log2sum + (int)(p / pix_per_item), log2((double)lk));
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b,
+                           float* __restrict__ out, int ld_out, long n_vec, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    float4 x = *reinterpret_cast<const float4*>(a + p * ld_a + c);
+    float4 y = *reinterpret_cast<const float4*>(b + p * ld_b + c);
+    *reinterpret_cast<float4*>(out + p * ld_out + c) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+__global__ void dequantize_kernel(const int32_t* __restrict__ sym, int ld_sym, const float* __restrict__ mu, int ld_mu,
+                                  float* __restrict__ out, int ld_out, long n_vec, int C4) {
+  // EntropyModel.dequantize (entropy_models.py:161-168): float(symbols) + means
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    int4 q = *reinterpret_cast<const int4*>(sym + p * ld_sym + c);
+    float4 m = mu ? *reinterpret_cast<const float4*>(mu + p * ld_mu + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + p * ld_out + c) = make_float4((float)q.x + m.x, (float)q.y + m.y, (float)q.z + m.z, (float)q.w + m.w);
+  }
+}
+
+__global__ void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, double* acc) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float d = a[i] - b[i];
+    s += (double)d * (double)d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+static inline unsigned stream_grid(long n_items, int block) {
+  long g = (n_items + block - 1) / block;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace vam
+
+using namespace vam;
+
+extern "C" {
+
+int vam_s2d_input(const float* x, float* out, int B, int H, int W, void* stream) {
+  VAM_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "vam_s2d_input: need even H,W");
+  long total = (long)B * (H / 2) * (W / 2) * 4;
+  ProfScope ps(VAM_FAM_MISC, (hipStream_t)stream, 0, 4.0 * ((double)B * 3 * H * W + (double)total * 4));
+  hipLaunchKernelGGL(s2d_input_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W);
+  return check_launch("s2d_input_kernel");
+}
+
+int vam_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int ld_dst, void* stream) {
+  VAM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && ld_dst >= C, "vam_nchw_to_nhwc: bad arguments");
+  VAM_REQUIRE(B <= 65535 && cdiv(C, 32) <= 65535, "vam_nchw_to_nhwc: grid too large");
+  dim3 grid(cdiv((long)H * W, 32), cdiv(C, 32), B);
+  ProfScope ps(VAM_FAM_MISC, (hipStream_t)stream, 0, 8.0 * (double)B * C * H * W);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H * W, ld_dst);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+int vam_nhwc_to_nchw(const float* src, int ld_src, float* dst, int B, int C, int H, int W, void* stream) {
+  VAM_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && ld_src >= C, "vam_nhwc_to_nchw: bad arguments");
+  VAM_REQUIRE(B <= 65535 && cdiv(C, 32) <= 65535, "vam_nhwc_to_nchw: grid too large");
+  dim3 grid(cdiv((long)H * W, 32), cdiv(C, 32), B);
+  ProfScope ps(VAM_FAM_MISC, (hipStream_t)stream, 0, 8.0 * (double)B * C * H * W);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, B, C, H * W);
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int vam_gauss_tail(const float* y, int ld_y, const float* y2, int ld_y2, const float* mu, int ld_mu,
+                   const float* sigma, int ld_sigma, const float* mask, int ld_mask, float* yhat, int ld_yhat,
+                   float* lik, int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
+                   int C, void* stream) {
+  VAM_REQUIRE(y && mu && sigma && n_pix > 0 && C > 0 && C % 4 == 0, "vam_gauss_tail: need y, mu, sigma and C %% 4 == 0");
+  VAM_REQUIRE(!log2sum || pix_per_item > 0, "vam_gauss_tail: pix_per_item");
+  VAM_REQUIRE(al16(y) && al16(mu) && al16(sigma) && al16(y2) && al16(mask) && al16(yhat) && al16(lik) && al16(sym), "vam_gauss_tail: 16-byte alignment");
+  VAM_REQUIRE(ld_y % 4 == 0 && ld_mu % 4 == 0 && ld_sigma % 4 == 0 && (!y2 || ld_y2 % 4 == 0) && (!mask || ld_mask % 4 == 0) && (!yhat || ld_yhat % 4 == 0) && (!lik || ld_lik % 4 == 0) && (!sym || ld_sym % 4 == 0), "vam_gauss_tail: strides must be multiples of 4");
+  TailArgs a;
+  a.y = y; a.y2 = y2; a.mu = mu; a.sigma = sigma; a.mask = mask; a.yhat = yhat; a.lik = lik; a.sym = sym;
+  a.log2sum = log2sum;
+  a.ld_y = ld_y; a.ld_y2 = ld_y2; a.ld_mu = ld_mu; a.ld_sigma = ld_sigma; a.ld_mask = ld_mask;
+  a.ld_yhat = ld_yhat; a.ld_lik = ld_lik; a.ld_sym = ld_sym;
+  a.pix_per_item = pix_per_item; a.C4 = C / 4; a.n_vec = n_pix * (C / 4);
+  int nin = 3 + (y2 ? 1 : 0) + (mask ? 1 : 0), nout = (yhat ? 1 : 0) + (lik ? 1 : 0) + (sym ? 1 : 0);
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 4.0 * (double)n_pix * C * (nin + nout));
+  hipLaunchKernelGGL(gauss_tail_kernel, dim3(stream_grid(a.n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("gauss_tail_kernel");
+}
+
+int vam_build_indexes(const float* sigma, int ld_sigma, const float* mask, int ld_mask, const float* table,
+                      int n_table, int32_t* idx, int ld_idx, long n_pix, int C, void* stream) {
+  VAM_REQUIRE(sigma && table && idx && n_pix > 0 && C > 0 && C % 4 == 0, "vam_build_indexes: bad arguments");
+  VAM_REQUIRE(n_table >= 2 && n_table <= 256, "vam_build_indexes: table size %d", n_table);
+  VAM_REQUIRE(al16(sigma) && al16(mask) && al16(idx) && ld_sigma % 4 == 0 && ld_idx % 4 == 0 && (!mask || ld_mask % 4 == 0), "vam_build_indexes: alignment");
+  long n_vec = n_pix * (C / 4);
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 4.0 * (double)n_pix * C * (mask ? 3 : 2));
+  hipLaunchKernelGGL(build_indexes_kernel, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, sigma,
+                     ld_sigma, mask, ld_mask, table, n_table, idx, ld_idx, n_vec, C / 4);
+  return check_launch("build_indexes_kernel");
+}
+
+int vam_eb_forward(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat, float* lik,
+                   int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix, void* stream) {
+  return vam_eb_forward_noise(z, ld_z, params, C, zhat, ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix,
+                              nullptr, 0, stream);
+}
+
+int vam_eb_forward_noise(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat, float* lik,
+                         int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
+                         const float* noise, int ld_noise, void* stream) {
+  VAM_REQUIRE(!noise || ld_noise >= C, "vam_eb_forward_noise: noise stride");
+  VAM_REQUIRE(z && params && C > 0 && C <= 1024 && n_pix > 0, "vam_eb_forward: bad arguments");
+  VAM_REQUIRE(!log2sum || pix_per_item > 0, "vam_eb_forward: pix_per_item");
+  int block = (C + 63) / 64 * 64;
+  size_t smem = (size_t)C * 62 * sizeof(float);
+  VAM_REQUIRE(smem <= 64 * 1024, "vam_eb_forward: C too large for LDS staging");
+  unsigned grid = (unsigned)(n_pix < 1024 ? n_pix : 1024);
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
+  hipLaunchKernelGGL(eb_forward_kernel, dim3(grid), dim3(block), smem, (hipStream_t)stream, z, ld_z, params, C, zhat,
+                     ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix, noise, ld_noise);
+  return check_launch("eb_forward_kernel");
+}
+
+int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, long n_pix, int C,
+            void* stream) {
+  VAM_REQUIRE(a && b && out && n_pix > 0 && C > 0 && C % 4 == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_out % 4 == 0, "vam_add: bad arguments");
+  VAM_REQUIRE(al16(a) && al16(b) && al16(out), "vam_add: alignment");
+  long n_vec = n_pix * (C / 4);
+  ProfScope ps(VAM_FAM_MISC, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
+  hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, ld_a, b, ld_b,
+                     out, ld_out, n_vec, C / 4);
+  return check_launch("add_kernel");
+}
+
+int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, float* out, int ld_out, long n_pix, int C,
+                   void* stream) {
+  VAM_REQUIRE(sym && out && n_pix > 0 && C > 0 && C % 4 == 0 && ld_sym % 4 == 0 && ld_out % 4 == 0 && (!mu || ld_mu % 4 == 0), "vam_dequantize: bad arguments");
+  VAM_REQUIRE(al16(sym) && al16(mu) && al16(out), "vam_dequantize: alignment");
+  long n_vec = n_pix * (C / 4);
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 12.0 * (double)n_pix * C);
+  hipLaunchKernelGGL(dequantize_kernel, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, sym, ld_sym, mu,
+                     ld_mu, out, ld_out, n_vec, C / 4);
+  return check_launch("dequantize_kernel");
+}
+
+int vam_memset_zero(void* ptr, size_t bytes, void* stream) {
+  VAM_REQUIRE(ptr && bytes > 0, "vam_memset_zero: bad arguments");
+  VAM_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream));
+  return VAM_OK;
+}
+
+int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream) {
+  VAM_REQUIRE(a && b && acc && n > 0, "vam_sqdiff_sum: bad arguments");
+  ProfScope ps(VAM_FAM_MISC, (hipStream_t)stream, 0, 8.0 * (double)n);
+  hipLaunchKernelGGL(sqdiff_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, acc);
+  return check_launch("sqdiff_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// Backward kernels for the REM fine-tune step (BASELINE configs[4]: `--training_type rems`,
+// reference train.py:223-226 freezes everything except `post_latent`, loss = RateLoss).  Only the
+// Rate-Enhancement blocks train, so the backward pass is: noisy Gaussian likelihood -> (mu', sigma')
+// -> LatentRateReduction (conv3x3 / LeakyReLU / 1x1 skips, reference layers/rem.py:37-141).
+//   * data gradients of a convolution reuse conv_igemm_kernel with weights repacked by
+//     vam_pack_conv_weights(VAM_PACK_CONV_DGRAD) (channels swapped, taps flipped);
+//   * weight gradients: wgrad_kernel below (GEMM over pixels on the fp32 matrix cores);
+//   * element-wise pieces: LeakyReLU backward, products, and the likelihood's forward (with
+//     additive uniform noise, entropy_models.py:132-138,620-652) and backward (incl. compressai's
+//     LowerBound gradient rule).
+// These layers are 32-96 channels on a 16x16 latent grid: 0.3 % of the step's FLOPs, so the
+// kernels are written for clarity and determinism (fixed reduction order, no float atomics).
+#include "common.h"
+
+namespace vam {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// dW[n][c_off + c][ty][tx] = sum_p dY[p][n] * X[pix(p) + (ty - pad, tx - pad)][c]      (stride 1)
+// grid = (taps * N/32 tiles * C/32 tiles [max over the group], problems).  8 waves split the pixels in batches of
+// 32 (16 MFMAs with all 32 loads of a batch in flight: the loop is latency-bound otherwise); fixed-order LDS
+// reduction.  The block of tap 0 / channel tile 0 / c_off 0 also produces db[n] = sum_p dY[p][n].
+constexpr int WG_WAVES = 8, WG_BATCH = 16;   // MFMAs per batch; each covers 2 pixels
+
+struct WgradArgs {
+  vam_wgrad p[VAM_MAX_WGRAD_GROUP];
+};
+
+__global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs args) {
+  __shared__ float red[WG_WAVES][32][33];
+  __shared__ float redb[WG_WAVES][2][32];
+  const vam_wgrad& pr = args.p[blockIdx.y];
+  const int kh = pr.kh, kw = pr.kw, taps = kh * kw;
+  const int n_tiles = (pr.N + 31) / 32, c_tiles = (pr.C + 31) / 32;
+  int bid = blockIdx.x;
+  if (bid >= taps * n_tiles * c_tiles) return;
+  const int tap = bid % taps;
+  bid /= taps;
+  const int n0 = (bid % n_tiles) * 32, c0 = (bid / n_tiles) * 32;
+  const int ty = tap / kw, tx = tap % kw, pad_y = kh / 2, pad_x = kw / 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int H = pr.H, W = pr.W, HW = H * W;
+  const long P = (long)pr.B * HW;
+  const float* __restrict__ x = pr.x;
+  const float* __restrict__ dy = pr.dy;
+  const int ld_x = pr.ld_x, ld_dy = pr.ld_dy;
+  const bool n_ok = n0 + l31 < pr.N, c_ok = c0 + l31 < pr.C;
+  const bool want_db = pr.db != nullptr && tap == 0 && c0 == 0 && pr.c_off == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (long pb = (long)wid * (2 * WG_BATCH); pb < P; pb += (long)WG_WAVES * 2 * WG_BATCH) {
+    float a[WG_BATCH], b[WG_BATCH];
+#pragma unroll
+    for (int i = 0; i < WG_BATCH; ++i) {
+      const long p = pb + 2 * i + lh;
+      a[i] = 0.f;
+      b[i] = 0.f;
+      if (p < P) {
+        if (n_ok) a[i] = dy[p * ld_dy + n0 + l31];
+        const int bi = (int)(p / HW);
+        const int r = (int)(p - (long)bi * HW);
+        const int oy = r / W, ox = r - oy * W;
+        const int iy = oy - pad_y + ty, ix = ox - pad_x + tx;
+        if (c_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          b[i] = x[((long)bi * HW + (long)iy * W + ix) * ld_x + c0 + l31];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WG_BATCH; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+      bsum += a[i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
+  redb[wid][lh][l31] = bsum;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += WG_WAVES * 64) {
+    const int n = i >> 5, c = i & 31;
+    if (n0 + n < pr.N && c0 + c < pr.C) {
+      float v = red[0][n][c];
+#pragma unroll
+      for (int k = 1; k < WG_WAVES; ++k) v += red[k][n][c];
+      pr.dw[(((long)(n0 + n) * pr.cin_total + pr.c_off + c0 + c) * kh + ty) * kw + tx] = v;
+    }
+  }
+  if (want_db && threadIdx.x < 32 && n0 + threadIdx.x < pr.N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < WG_WAVES; ++k) v += redb[k][0][threadIdx.x] + redb[k][1][threadIdx.x];
+    pr.db[n0 + threadIdx.x] = v;
+  }
+}
+
+// db[n] = sum_p dY[p][n]  (one block per 32 channels, fixed order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int ld, long P, int N,
+                                                     float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int n = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.f;
+  if (n < N)
+    for (long p = g; p < P; p += 8) s += dy[p * ld + n];
+  red[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    out[n] = t;
+  }
+}
+
+__global__ void leaky_bwd_kernel(const float* __restrict__ act, int ld_a, const float* __restrict__ dy, int ld_dy,
+                                 float* __restrict__ dx, int ld_dx, long n_vec, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    float4 a = *reinterpret_cast<const float4*>(act + p * ld_a + c);
+    float4 g = *reinterpret_cast<const float4*>(dy + p * ld_dy + c);
+    *reinterpret_cast<float4*>(dx + p * ld_dx + c) =
+        make_float4(g.x * (a.x > 0.f ? 1.f : 0.01f), g.y * (a.y > 0.f ? 1.f : 0.01f), g.z * (a.z > 0.f ? 1.f : 0.01f),
+                    g.w * (a.w > 0.f ? 1.f : 0.01f));
+  }
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b,
+                           float* __restrict__ out, int ld_out, long n_vec, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / C4;
+    int c = (int)(i - p * C4) * 4;
+    float4 x = *reinterpret_cast<const float4*>(a + p * ld_a + c);
+    float4 y = *reinterpret_cast<const float4*>(b + p * ld_b + c);
+    *reinterpret_cast<float4*>(out + p * ld_out + c) = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+  }
+}
+
+// ---- training-mode Gaussian likelihood (additive-noise quantisation proxy)
+//   v   = ((y - y2) - mu) * m + noise          (progressive: pic.py:437-442 / rem_pic.py:387-390; m, y2 optional)
+//   s   = max(sigma * m, 0.11)                  LowerBound
+//   lik = max(Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), 1e-9)
+struct LikArgs {
+  const float *y, *y2, *mu, *sigma, *mask, *noise, *glik;
+  float *lik, *dmu, *dsigma;
+  int ld_y, ld_y2, ld_mu, ld_sigma, ld_mask, ld_noise, ld_glik, ld_lik, ld_dmu, ld_dsigma, C4;
+  long n_vec;
+};
+
+__device__ __forceinline__ float phi_cdf(float t) { return 0.5f * erfcf(-0.70710678118654752440f * t); }
+__device__ __forceinline__ float phi_pdf(float t) { return 0.3989422804014327f * expf(-0.5f * t * t); }
+
+template <bool BWD>
+__global__ void gauss_train_kernel(const LikArgs a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_vec; i += (long)gridDim.x * blockDim.x) {
+    long p = i / a.C4;
+    int c = (int)(i - p * a.C4) * 4;
+    float4 y4 = *reinterpret_cast<const float4*>(a.y + p * a.ld_y + c);
+    if (a.y2) {
+      float4 t = *reinterpret_cast<const float4*>(a.y2 + p * a.ld_y2 + c);
+      y4.x -= t.x; y4.y -= t.y; y4.z -= t.z; y4.w -= t.w;
+    }
+    const float4 mu4 = *reinterpret_cast<const float4*>(a.mu + p * a.ld_mu + c);
+    const float4 sg4 = *reinterpret_cast<const float4*>(a.sigma + p * a.ld_sigma + c);
+    const float4 nz4 = *reinterpret_cast<const float4*>(a.noise + p * a.ld_noise + c);
+    float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.mask) m4 = *reinterpret_cast<const float4*>(a.mask + p * a.ld_mask + c);
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BWD) g4 = *reinterpret_cast<const float4*>(a.glik + p * a.ld_glik + c);
+    const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+    const float nv[4] = {nz4.x, nz4.y, nz4.z, nz4.w}, kv[4] = {m4.x, m4.y, m4.z, m4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o0[4], o1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = yv[k] - mv[k];
+      const float v = a.mask ? d * kv[k] + nv[k] : d + nv[k];
+      const float raw_s = a.mask ? sv[k] * kv[k] : sv[k];
+      const float s = fmaxf(raw_s, 0.11f);
+      const float av = fabsf(v);
+      const float u = (0.5f - av) / s, l = (-0.5f - av) / s;
+      const float lik_raw = phi_cdf(u) - phi_cdf(l);
+      if (!BWD) {
+        o0[k] = fmaxf(lik_raw, 1e-9f);
+      } else {
+        // LowerBound backward: pass where x >= bound or the incoming gradient is negative
+        float g = gv[k];
+        if (!(lik_raw >= 1e-9f || g < 0.f)) g = 0.f;
+        const float pu = phi_pdf(u), pl = phi_pdf(l);
+        const float dlik_dv = (av == 0.f ? 0.f : (v > 0.f ? 1.f : -1.f)) * (pl - pu) / s;      // d|v|/dv * dlik/d|v|
+        float gs = g * (pl * l - pu * u) / s;                                                 // dlik/ds = (-pu*u + pl*l)/s
+        if (!(raw_s >= 0.11f || gs < 0.f)) gs = 0.f;                                          // LowerBound(0.11) rule
+        o0[k] = -g * dlik_dv * kv[k];        // d/dmu : v = (.. - mu) * m
+        o1[k] = gs * kv[k];                  // d/dsigma: s = sigma * m
+      }
+    }
+    if (!BWD) {
+      *reinterpret_cast<float4*>(a.lik + p * a.ld_lik + c) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    } else {
+      *reinterpret_cast<float4*>(a.dmu + p * a.ld_dmu + c) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+      *reinterpret_cast<float4*>(a.dsigma + p * a.ld_dsigma + c) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+  }
+}
+
+static inline unsigned sgrid(long n, int block) {
+  long g = (n + block - 1) / block;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+static bool a16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace vam
+
+using namespace vam;
+
+extern "C" {
+
+int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
+  VAM_REQUIRE(probs && n_probs >= 1 && n_probs <= VAM_MAX_WGRAD_GROUP, "vam_conv_wgrad_group: 1..%d problems", VAM_MAX_WGRAD_GROUP);
+  int max_blocks = 0;
+  double flops = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    const vam_wgrad& p = probs[i];
+    VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
+    VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (stride 1, pad k/2)");
+    VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
+    int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
+    max_blocks = nb > max_blocks ? nb : max_blocks;
+    flops += 2.0 * p.B * p.H * p.W * (double)p.C * p.N * p.kh * p.kw;
+  }
+  WgradArgs wa;
+  for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
+  ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
+  return check_launch("wgrad_kernel");
+}
+
+int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw, int C,
+                   int N, float* dw, float* db, int cin_total, int c_off, void* stream) {
+  vam_wgrad p;
+  p.x = x; p.dy = dy; p.dw = dw; p.db = db;
+  p.ld_x = ld_x; p.ld_dy = ld_dy; p.B = B; p.H = H; p.W = W; p.kh = kh; p.kw = kw; p.C = C; p.N = N;
+  p.cin_total = cin_total; p.c_off = c_off;
+  return vam_conv_wgrad_group(&p, 1, stream);
+}
+
+int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream) {
+  VAM_REQUIRE(dy && out && n_pix > 0 && N > 0 && ld >= N, "vam_colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, (hipStream_t)stream, dy, ld, n_pix, N, out);
+  return check_launch("colsum_kernel");
+}
+
+int vam_leaky_bwd(const float* act, int ld_a, const float* dy, int ld_dy, float* dx, int ld_dx, long n_pix, int C,
+                  void* stream) {
+  VAM_REQUIRE(act && dy && dx && n_pix > 0 && C > 0 && C % 4 == 0 && ld_a % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0 && a16(act) && a16(dy) && a16(dx), "vam_leaky_bwd: bad arguments");
+  long n_vec = n_pix * (C / 4);
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(sgrid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, act, ld_a, dy, ld_dy, dx, ld_dx, n_vec, C / 4);
+  return check_launch("leaky_bwd_kernel");
+}
+
+int vam_mul(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, long n_pix, int C, void* stream) {
+  VAM_REQUIRE(a && b && out && n_pix > 0 && C > 0 && C % 4 == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_out % 4 == 0 && a16(a) && a16(b) && a16(out), "vam_mul: bad arguments");
+  long n_vec = n_pix * (C / 4);
+  hipLaunchKernelGGL(mul_kernel, dim3(sgrid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, ld_a, b, ld_b, out, ld_out, n_vec, C / 4);
+  return check_launch("mul_kernel");
+}
+
+int vam_gauss_train(const float* y, int ld_y, const float* y2, int ld_y2, const float* mu, int ld_mu, const float* sigma,
+                    int ld_sigma, const float* mask, int ld_mask, const float* noise, int ld_noise, const float* grad_lik,
+                    int ld_glik, float* lik, int ld_lik, float* dmu, int ld_dmu, float* dsigma, int ld_dsigma, long n_pix,
+                    int C, void* stream) {
+  VAM_REQUIRE(y && mu && sigma && noise && n_pix > 0 && C > 0 && C % 4 == 0, "vam_gauss_train: bad arguments");
+  const bool bwd = grad_lik != nullptr;
+  VAM_REQUIRE(bwd ? (dmu && dsigma) : (lik != nullptr), "vam_gauss_train: forward needs lik, backward needs dmu and dsigma");
+  LikArgs a;
+  a.y = y; a.y2 = y2; a.mu = mu; a.sigma = sigma; a.mask = mask; a.noise = noise; a.glik = grad_lik;
+  a.lik = lik; a.dmu = dmu; a.dsigma = dsigma;
+  a.ld_y = ld_y; a.ld_y2 = ld_y2; a.ld_mu = ld_mu; a.ld_sigma = ld_sigma; a.ld_mask = ld_mask; a.ld_noise = ld_noise;
+  a.ld_glik = ld_glik; a.ld_lik = ld_lik; a.ld_dmu = ld_dmu; a.ld_dsigma = ld_dsigma;
+  a.C4 = C / 4; a.n_vec = n_pix * (C / 4);
+  VAM_REQUIRE(a16(y) && a16(y2) && a16(mu) && a16(sigma) && a16(mask) && a16(noise) && a16(grad_lik) && a16(lik) && a16(dmu) && a16(dsigma), "vam_gauss_train: alignment");
+  VAM_REQUIRE(ld_y % 4 == 0 && ld_mu % 4 == 0 && ld_sigma % 4 == 0 && ld_noise % 4 == 0 && (!y2 || ld_y2 % 4 == 0) && (!mask || ld_mask % 4 == 0) && (!bwd || (ld_glik % 4 == 0 && ld_dmu % 4 == 0 && ld_dsigma % 4 == 0)) && (bwd || ld_lik % 4 == 0), "vam_gauss_train: strides");
+  ProfScope ps(VAM_FAM_TAIL, (hipStream_t)stream, 0, 4.0 * (double)n_pix * C * 8);
+  if (bwd) hipLaunchKernelGGL((gauss_train_kernel<true>), dim3(sgrid(a.n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((gauss_train_kernel<false>), dim3(sgrid(a.n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("gauss_train_kernel");
+}
+
+}  // extern "C"

@@ -206,34 +206,11 @@ def _out_extent(m, v: View):
 P3_MAX_PIXELS = 16384
 
 
-def lower_stack_heads(plan: Plan, stacks: Sequence[nn.Sequential], hyper_inputs: Sequence[View],
-                      has_support: Sequence[bool]) -> Dict[int, tuple]:
-    """The first layer of every slice stack reads cat(hyperprior tensor [c_head ch], supports...) (pic.py:528-529,
-    598-599,635).  Its hyperprior part does not depend on the slice loop, so it is computed for ALL stacks up front in
-    large grouped launches:  head_k = bias_k + conv(hyper; W_k[:, :c_head]);  inside the loop the first layer becomes
-    act(head_k + conv(supports; W_k[:, c_head:])) — the same sum in a different association (the split is the same
-    for encoder and decoder, so their bits still agree).  A stack without supports gets its complete first layer.
-    Returns {id(stack): (view, complete)}."""
-    heads: Dict[int, tuple] = {}
-    probs = []
-    for st, hv, sup in zip(stacks, hyper_inputs, has_support):
-        m, act = conv_layers(st)[0]
-        head, tail = m.packed_split(hv.C)
-        assert (tail is not None) == bool(sup), "stack input width does not match its supports"
-        o = plan.buf(hv.B, hv.H, hv.W, m.out_channels)
-        probs.append(ops.conv_problem(head, [hv], o, L.ACT_NONE if sup else act))
-        heads[id(st)] = (o, not sup)
-    plan.conv(probs)
-    return heads
-
-
 def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[Sequence[View]],
-                 outs: Sequence[Optional[View]], final: Optional[Sequence[dict]] = None,
-                 heads: Optional[Dict[int, tuple]] = None) -> List[View]:
+                 outs: Sequence[Optional[View]], final: Optional[Sequence[dict]] = None) -> List[View]:
     """Run K structurally identical conv stacks in lockstep: layer d of every stack is one
     grouped launch.  ``final[k]`` = extra epilogue kwargs (act/pre/mul/post/post2) of the last
-    layer of stack k.  ``heads`` (from :func:`lower_stack_heads`): the first layer's hyperprior part is already
-    there — ``inputs[k]`` then lists the supports only.  Returns the output views."""
+    layer of stack k.  Returns the output views."""
     K = len(stacks)
     lay = [conv_layers(s) for s in stacks]
     depth = len(lay[0])
@@ -248,11 +225,6 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
         nxt = []
         for k in range(K):
             m, act = lay[k][d]
-            hd = heads.get(id(stacks[k])) if (heads is not None and d == 0) else None
-            if hd is not None and hd[1]:             # complete first layer came with the heads
-                assert not cur[k]
-                nxt.append([hd[0]])
-                continue
             v0 = cur[k][0]
             Ho, Wo, Co = _out_extent(m, v0)
             last = d == depth - 1
@@ -266,17 +238,11 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
             if last and final is not None and final[k]:
                 kw = dict(final[k])
                 act = kw.pop("act", act)
-            if hd is not None:                        # supports only; the hyperprior part (with the bias) enters as `pre`
-                assert "pre" not in kw
-                c_head = m.in_channels - sum(v.C for v in cur[k])
-                probs.append(ops.conv_problem(m.packed_split(c_head)[1], cur[k], o, act, pre=hd[0], **kw))
-            else:
-                probs.append(ops.conv_problem(m.packed(), cur[k], o, act, **kw))
+            probs.append(ops.conv_problem(m.packed(), cur[k], o, act, **kw))
             nxt.append([o])
             if last:
                 res.append(o)
-        if probs:
-            plan.conv(probs)
+        plan.conv(probs)
         cur = nxt
     return res
 

@@ -67,19 +67,6 @@ class Conv2d(_Packable):
     def is_rgb_s2d(self):
         return self.in_channels == 3 and self.kernel_size == 5 and self.stride == 2
 
-    def packed_split(self, c_head: int):
-        """(head, tail): the layer as  conv(x[:, :c_head]; W[:, :c_head], bias) + conv(x[:, c_head:]; W[:, c_head:]).
-        ``tail`` is None when the layer has no input channels beyond ``c_head``.  Used to hoist the hyperprior part of
-        every slice stack's first layer out of the sequential slice loop (engine.lower_stack_heads)."""
-        key = (self._key(), c_head)
-        if getattr(self, "_pk_split_key", None) != key:
-            w = self.weight.detach()
-            head = ops.pack_conv(w[:, :c_head].contiguous(), self.bias, self.stride)
-            tail = ops.pack_conv(w[:, c_head:].contiguous(), None, self.stride) if self.in_channels > c_head else None
-            object.__setattr__(self, "_pk_split", (head, tail))
-            object.__setattr__(self, "_pk_split_key", key)
-        return self._pk_split
-
     def forward(self, x):
         from . import engine
         return engine.run_module(self, x)

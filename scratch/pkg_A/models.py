@@ -540,28 +540,6 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
 
 
 # ----------------------------------------------------------------------------- the fused plan
-def _slice_stack_heads(plan, m, means_h, scales_h, which):
-    """Hyperprior part of the first layer of every slice stack (engine.lower_stack_heads): base stacks read the first
-    ``d`` channels of the hyper tensors, progressive ones the second (pic.py:528-529,598-599); the LRP stacks share the
-    MEAN support of their slice (pic.py:548,635).  ``which`` = "base" or "prog".  Encoder and decoder plans both call
-    this, so both associate the first-layer sum the same way."""
-    d, ns = m.division_dimension[0], m.ns0
-    stacks, hyp, sup = [], [], []
-    if which == "base":
-        mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
-        for i in range(ns):
-            stacks += [m.cc_mean_transforms[i], m.cc_scale_transforms[i], m.lrp_transforms[i]]
-            hyp += [mh0, sh0, mh0]
-            sup += [i > 0, i > 0, True]
-    else:
-        mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
-        for j in range(ns):
-            stacks += [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j], m.lrp_transforms_prog[j]]
-            hyp += [mh1, sh1, mh1]
-            sup += [True, True, True]
-    return E.lower_stack_heads(plan, stacks, hyp, sup)
-
-
 def _version_sig(mod: nn.Module):
     return tuple(p._version for p in mod.parameters())
 
@@ -647,14 +625,12 @@ class _FsqPlan:
         plan.keep += [self.sym, self.idx]
         sl = lambda v, i, n=1: v.window(i * C, n * C)
         mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
-        hyper_done = plan.record() if not base_only else None
-        heads = _slice_stack_heads(plan, m, means_h, scales_h, "base")     # hyperprior part of every first layer, up front
 
         def base_group(idx: List[int]):
             sup = [sl(yb, 0, min(m.max_support_slices, idx[0]))] if idx[0] > 0 else []
             E.lower_stacks(plan, [m.cc_mean_transforms[i] for i in idx] + [m.cc_scale_transforms[i] for i in idx],
-                           [sup] * (2 * len(idx)),
-                           [sl(self.mu_b, i) for i in idx] + [sl(self.std_b, i) for i in idx], heads=heads)
+                           [[mh0] + sup] * len(idx) + [[sh0] + sup] * len(idx),
+                           [sl(self.mu_b, i) for i in idx] + [sl(self.std_b, i) for i in idx])
             i0, n = idx[0], len(idx)
             plan.call(lambda: ops.gauss_tail(sl(y, i0, n), sl(self.mu_b, i0, n), sl(self.std_b, i0, n),
                                              yhat=sl(yq, i0, n), lik=sl(self.lik, i0, n), log2sum=ls_y,
@@ -664,9 +640,9 @@ class _FsqPlan:
                                                   sl(self.noise_y, i0, n), lik=sl(self.lik, i0, n)))
             if indexes:                                                               # pic.py:737
                 plan.call(lambda: ops.build_indexes(sl(self.std_b, i0, n), table, out=sl(self.idx, i0, n)))
-            E.lower_stacks(plan, [m.lrp_transforms[i] for i in idx], [sup + [sl(yq, i)] for i in idx],
+            E.lower_stacks(plan, [m.lrp_transforms[i] for i in idx], [[mh0] + sup + [sl(yq, i)] for i in idx],
                            [sl(yb, i) for i in idx],
-                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i)) for i in idx], heads=heads)
+                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i)) for i in idx])
 
         base_done = {}                                   # slice -> event "its y_hat_base is final"
         for i in range(min(ns, m.max_support_slices)):
@@ -695,17 +671,15 @@ class _FsqPlan:
         # With all_scalable the progressive mu/sigma chain only needs y_hat_base[j] and its own history
         # (pic.py:586-612), so it runs on a second HIP stream concurrently with base slices > j.
         plan.branch(1)
-        plan.wait(hyper_done)
-        heads.update(_slice_stack_heads(plan, m, means_h, scales_h, "prog"))   # on the chain's stream, beside base slice 0
         for j in range(ns):
             plan.wait(base_done[j])
             s = min(sp, j)
-            ms = [sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else [])          # supports; the hyperprior part is in `heads`
-            ss = [sl(yb, j)] + ([sl(self.std_p, j - s, s)] if s else [])
+            ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else [])
+            ss = [sh1, sl(yb, j)] + ([sl(self.std_p, j - s, s)] if s else [])
             msups.append(ms)
             ssups.append(ss)
             E.lower_stacks(plan, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss],
-                           [sl(self.mu_p, j), sl(self.std_p, j)], heads=heads)
+                           [sl(self.mu_p, j), sl(self.std_p, j)])
             plan.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)))       # pic.py:603
         chain_done = plan.record()
         plan.branch(0)
@@ -723,7 +697,7 @@ class _FsqPlan:
                                                  yhat=rq_ck, lik=junk))
                 E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)],
                                [msups[j] + [sl(rq_ck, j)] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
-                               [dict(act=L.ACT_HALF_TANH, post=sl(rq_ck, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)
+                               [dict(act=L.ACT_HALF_TANH, post=sl(rq_ck, j), post2=sl(yb, j)) for j in range(ns)])
             att = plan.buf(B, h, w, d)
             plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
             mu_f, std_f = plan.buf(B, h, w, d), plan.buf(B, h, w, d)
@@ -774,7 +748,7 @@ class _FsqPlan:
         yp = self.y_prog = plan.buf(B, h, w, d)
         E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
                        [sl(yp, j) for j in range(ns)],
-                       [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
+                       [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)])   # :635-641
         if not symbols:
             E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
 
@@ -897,10 +871,8 @@ class _DecPlan:
         P.call(lambda: ops.dequantize(self.z_sym, med, z_hat))                       # entropy_models.py:520-525
         E.lower_stacks(P, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)], [[z_hat]] * (2 * nh),
                        [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
-        heads = _slice_stack_heads(P, m, means_h, scales_h, "base")                 # same association as the encoder's plan
-        if not base_only:
-            heads.update(_slice_stack_heads(P, m, means_h, scales_h, "prog"))
         # ---- base slices
+        mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
         yq, yb, mu_b, std_b = nv(d), nv(d), nv(d), nv(d)
         self.idx_b, self.sym_b = ni(d), ni(d)
         self.mu_b, self.std_b = mu_b, std_b
@@ -908,12 +880,12 @@ class _DecPlan:
         for i in range(ns):
             sup = [sl(yb, 0, min(m.max_support_slices, i))] if i > 0 else []
             Pa, Pb = E.Plan(device), E.Plan(device)
-            E.lower_stacks(Pa, [m.cc_mean_transforms[i], m.cc_scale_transforms[i]], [sup, sup],
-                           [sl(mu_b, i), sl(std_b, i)], heads=heads)
+            E.lower_stacks(Pa, [m.cc_mean_transforms[i], m.cc_scale_transforms[i]], [[mh0] + sup, [sh0] + sup],
+                           [sl(mu_b, i), sl(std_b, i)])
             Pa.call(lambda i=i: ops.build_indexes(sl(std_b, i), table, out=sl(self.idx_b, i)))          # pic.py:879
             Pb.call(lambda i=i: ops.dequantize(sl(self.sym_b, i), sl(mu_b, i), sl(yq, i)))               # pic.py:884
-            E.lower_stacks(Pb, [m.lrp_transforms[i]], [sup + [sl(yq, i)]], [sl(yb, i)],
-                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i))], heads=heads)
+            E.lower_stacks(Pb, [m.lrp_transforms[i]], [[mh0] + sup + [sl(yq, i)]], [sl(yb, i)],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(yq, i))])
             self.p_base.append((Pa, Pb))
         self.p_syn = E.Plan(device)
         if base_only:
@@ -930,11 +902,10 @@ class _DecPlan:
         self.p_prog = []
         for j in range(ns):
             s_ = min(sp, j)
-            ms = [sl(yb, j)] + ([sl(mu_tot, j - s_, s_)] if s_ else [])
-            ss = [sl(yb, j)] + ([sl(std_p, j - s_, s_)] if s_ else [])
+            ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s_, s_)] if s_ else [])
+            ss = [sh1, sl(yb, j)] + ([sl(std_p, j - s_, s_)] if s_ else [])
             Pa, Pb = E.Plan(device), E.Plan(device)
-            E.lower_stacks(Pa, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss], [sl(mu_p, j), sl(std_p, j)],
-                           heads=heads)
+            E.lower_stacks(Pa, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss], [sl(mu_p, j), sl(std_p, j)])
             Pa.call(lambda j=j: ops.add(sl(mu_p, j), sl(yb, j), sl(mu_tot, j)))
             if rem_idx is not None:
                 Pa.call(lambda j=j: ops.variance_mask(sl(std_p, j), self.pr, sl(att, j), n_slice=1))
@@ -944,7 +915,7 @@ class _DecPlan:
             Pa.call(lambda j=j: ops.build_indexes(sl(std_f, j), table, mask=sl(mask, j), out=sl(self.idx_p, j)))  # :945
             Pb.call(lambda j=j: ops.dequantize(sl(self.sym_p, j), sl(mu_f, j), sl(rq, j)))               # :948
             E.lower_stacks(Pb, [m.lrp_transforms_prog[j]], [ms + [sl(rq, j)]], [sl(yp, j)],
-                           [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))], heads=heads)
+                           [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))])
             self.p_prog.append((Pa, Pb))
         E.lower_g_s(self.p_syn, [m.g_s[1]], [yp], [self.x_hat])
 

@@ -1,0 +1,503 @@
+"""Thin host-side wrappers over the C ABI.
+
+``View`` is a channel window of an NHWC fp32 device buffer (``[B,H,W,ld]`` with
+``C <= ld`` channels starting at ``c0``).  torch only owns the memory and the stream;
+every arithmetic op below is a libvampic call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class View:
+    buf: torch.Tensor   # [B, H, W, ld] fp32 contiguous, cuda
+    c0: int
+    C: int
+
+    @property
+    def B(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3]
+    @property
+    def ptr(self): return self.buf.data_ptr() + 4 * self.c0
+    @property
+    def n_pix(self): return self.B * self.H * self.W
+
+    def window(self, c0: int, C_: int) -> "View":
+        assert 0 <= c0 and c0 + C_ <= self.C, (c0, C_, self.C)
+        return View(self.buf, self.c0 + c0, C_)
+
+    def torch_nchw(self) -> torch.Tensor:
+        """Logical NCHW tensor sharing this window's memory (channels_last strides)."""
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+
+
+@dataclass
+class View3:
+    """A channel window of a bf16x3-plane ("P3") tensor: [B, H, W, groups][plane 3][8 bf16], 48 bytes per 8-channel
+    group (stored in an fp32 tensor of 12 floats per group).  Written by a conv launch with VAM_CONV_OUT_BF3 and read
+    only by convolutions (VAM_CONV_IN_BF3): the exact hi/mid/lo split of each fp32 value, made once by the producer."""
+    buf: torch.Tensor   # [B, H, W, 12 * groups] fp32 storage
+    g0: int
+    C: int
+
+    @property
+    def B(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3] // 12      # groups per pixel
+    @property
+    def ptr(self): return self.buf.data_ptr() + 48 * self.g0
+    @property
+    def n_pix(self): return self.B * self.H * self.W
+
+    def window(self, c0: int, C_: int) -> "View3":
+        assert c0 % 8 == 0 and C_ % 8 == 0 and 0 <= c0 and c0 + C_ <= self.C
+        return View3(self.buf, self.g0 + c0 // 8, C_)
+
+    def to_float(self) -> torch.Tensor:
+        """Decode to a [B,H,W,C] fp32 tensor (hi + mid + lo; test / debug helper)."""
+        B, H, W = self.B, self.H, self.W
+        raw = self.buf.view(torch.int16).view(B, H, W, self.ld, 3, 8)[..., self.g0:self.g0 + self.C // 8, :, :]
+        planes = (raw.to(torch.int32) << 16).view(torch.float32)
+        return (planes[..., 0, :] + planes[..., 1, :] + planes[..., 2, :]).reshape(B, H, W, self.C)
+
+
+def new_view3(B: int, H: int, W: int, C_: int, device="cuda") -> View3:
+    assert C_ % 8 == 0
+    return View3(torch.zeros((B, H, W, (C_ // 8) * 12), dtype=torch.float32, device=device), 0, C_)
+
+
+def split_mode() -> bool:
+    """True when the convolution kernel runs on split bf16x3 operands (the default)."""
+    return L.load().vam_conv_get_mode() == 1
+
+
+def new_view(B: int, H: int, W: int, C_: int, device="cuda", zero: bool = False) -> View:
+    f = torch.zeros if zero else torch.empty
+    return View(f((B, H, W, C_), dtype=torch.float32, device=device), 0, C_)
+
+
+def from_nchw(x: torch.Tensor) -> View:
+    """NCHW (any strides) -> NHWC view.  Uses the layout kernel for plain-contiguous inputs;
+    a channels_last tensor is already NHWC in memory and is wrapped without a copy."""
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda, "expected a cuda fp32 NCHW tensor"
+    B, C_, H, W = x.shape
+    xp = x.permute(0, 2, 3, 1)
+    if xp.is_contiguous():
+        return View(xp, 0, C_)
+    x = x.contiguous()
+    out = new_view(B, H, W, C_)
+    L.check(L.load().vam_nchw_to_nhwc(x.data_ptr(), out.ptr, B, C_, H, W, out.ld, stream_ptr()), "vam_nchw_to_nhwc")
+    return out
+
+
+def to_nchw(v: View) -> torch.Tensor:
+    out = torch.empty((v.B, v.C, v.H, v.W), dtype=torch.float32, device=v.buf.device)
+    L.check(L.load().vam_nhwc_to_nchw(v.ptr, v.ld, out.data_ptr(), v.B, v.C, v.H, v.W, stream_ptr()), "vam_nhwc_to_nchw")
+    return out
+
+
+# --------------------------------------------------------------------------- weights
+@dataclass
+class Packed:
+    """A conv problem's constant part: packed weights + bias and its geometry."""
+    w: torch.Tensor
+    b: Optional[torch.Tensor]
+    kh: int
+    kw: int
+    cin: int
+    n: int
+    stride: int = 1
+    pad_y: int = 0
+    pad_x: int = 0
+    ps2_cq: int = 0          # >0: PixelShuffle-style phase scatter with Cq channels per phase
+    osy: int = 1
+    osx: int = 1
+    ooy: int = 0
+    oox: int = 0
+
+
+def pack_weights(src: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int) -> torch.Tensor:
+    lib = L.load()
+    src = src.detach().to(dtype=torch.float32).contiguous()
+    assert src.is_cuda
+    dst = torch.empty(lib.vam_conv_wpack_floats(kh, kw, cin, n), dtype=torch.float32, device=src.device)
+    L.check(lib.vam_pack_conv_weights(src.data_ptr(), dst.data_ptr(), mode, phase, kh, kw, cin, n, stream_ptr()),
+            "vam_pack_conv_weights")
+    return dst
+
+
+def repack_conv(conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], pk: "Packed", dgrad: bool = False):
+    """Refresh ``pk`` IN PLACE from the (trained) parameters: plans keep pointing at the same packed buffers
+    while the optimiser updates the weights between steps."""
+    lib = L.load()
+    assert conv_weight.is_cuda and conv_weight.is_contiguous() and conv_weight.dtype == torch.float32
+    mode = L.PACK_CONV_DGRAD if dgrad else L.PACK_CONV
+    L.check(lib.vam_pack_conv_weights(conv_weight.data_ptr(), pk.w.data_ptr(), mode, 0, pk.kh, pk.kw, pk.cin, pk.n,
+                                      stream_ptr()), "vam_pack_conv_weights")
+    if not dgrad and conv_bias is not None:
+        L.check(lib.vam_pack_bias(conv_bias.data_ptr(), pk.b.data_ptr(), L.PACK_CONV, pk.n, stream_ptr()), "vam_pack_bias")
+
+
+def pack_bias(src: torch.Tensor, mode: int, n: int) -> torch.Tensor:
+    lib = L.load()
+    src = src.detach().to(dtype=torch.float32).contiguous()
+    dst = torch.empty(n, dtype=torch.float32, device=src.device)
+    L.check(lib.vam_pack_bias(src.data_ptr(), dst.data_ptr(), mode, n, stream_ptr()), "vam_pack_bias")
+    return dst
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1) -> Packed:
+    """nn.Conv2d(k, stride, padding=k//2)  (reference layers/layers.py:5-12,24-26,77-79)."""
+    n, cin, kh, kw = weight.shape
+    return Packed(pack_weights(weight, L.PACK_CONV, 0, kh, kw, cin, n),
+                  None if bias is None else pack_bias(bias, L.PACK_CONV, n),
+                  kh, kw, cin, n, stride, kh // 2, kw // 2)
+
+
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
+    n, cin = weight.shape
+    return Packed(pack_weights(weight, L.PACK_CONV, 0, 1, 1, cin, n),
+                  None if bias is None else pack_bias(bias, L.PACK_CONV, n), 1, 1, cin, n)
+
+
+def pack_subpel(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
+    """conv3x3(Cin -> 4*Cq) + PixelShuffle(2)  (layers/layers.py:82-86)."""
+    n, cin, kh, kw = weight.shape
+    return Packed(pack_weights(weight, L.PACK_PS2, 0, kh, kw, cin, n), pack_bias(bias, L.PACK_PS2, n),
+                  kh, kw, cin, n, 1, kh // 2, kw // 2, ps2_cq=n // 4)
+
+
+def pack_conv5s2_rgb(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
+    """conv5x5 s2 pad2 on 3 input channels as a 3x3 s1 problem over the space-to-depth
+    input of vam_s2d_input (16 channels = (py,px,c) + 4 zeros).  Pure re-indexing of the
+    weights (a gather of existing values and zeros): w'[n,(py,px,c),ty,tx] = w[n,c,2ty+py,2tx+px]."""
+    n, cin, kh, kw = weight.shape
+    assert cin == 3 and kh == 5 and kw == 5
+    w6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=weight.device)
+    w6[:, :, :5, :5] = weight.detach()
+    w = w6.reshape(n, 3, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 12, 3, 3)   # [n,(py,px,c),ty,tx]
+    w16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=weight.device)
+    w16[:, :12] = w
+    return Packed(pack_weights(w16, L.PACK_CONV, 0, 3, 3, 16, n), pack_bias(bias, L.PACK_CONV, n),
+                  3, 3, 16, n, 1, 1, 1)
+
+
+def pack_deconv(weight: torch.Tensor, bias: torch.Tensor) -> List[Packed]:
+    """ConvTranspose2d(k5,s2,p2,op1) (layers/layers.py:14-22) as sub-pixel phase problems.
+    Cout % 4 == 0: four problems (taps 3x3,3x2,2x3,2x2) writing interleaved output pixels.
+    Otherwise (Cout = 3): one merged 3x3 problem with phase-major channels + PS2 scatter."""
+    cin, cout, kh, kw = weight.shape
+    assert kh == 5 and kw == 5
+    if cout % 4 == 0:
+        b = pack_bias(bias, L.PACK_CONV, cout)
+        out = []
+        for ph in range(4):
+            py, px = ph >> 1, ph & 1
+            k_h, k_w = (2 if py else 3), (2 if px else 3)
+            out.append(Packed(pack_weights(weight, L.PACK_DECONV5S2, ph, k_h, k_w, cin, cout), b, k_h, k_w, cin, cout,
+                              1, 0 if py else 1, 0 if px else 1, osy=2, osx=2, ooy=py, oox=px))
+        return out
+    n = 4 * cout
+    return [Packed(pack_weights(weight, L.PACK_DECONV5S2, -1, 3, 3, cin, n), pack_bias(bias, L.PACK_DECONV5S2, n),
+                   3, 3, cin, n, 1, 1, 1, ps2_cq=cout)]
+
+
+def pack_gdn(beta: torch.Tensor, gamma: torch.Tensor) -> Packed:
+    """GDN norm pool as a 1x1 problem on x^2 with the reparametrised gamma/beta (layers/gdn.py:62-69)."""
+    c = beta.shape[0]
+    return Packed(pack_weights(gamma, L.PACK_GDN, 0, 1, 1, c, c), pack_bias(beta, L.PACK_GDN, c), 1, 1, c, c)
+
+
+# --------------------------------------------------------------------------- conv problems
+def _aux(v: Optional[View]) -> L.VamAux:
+    a = L.VamAux()
+    if v is not None:
+        a.ptr = v.ptr
+        a.ld = v.ld
+    return a
+
+
+def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT_NONE, *,
+                 pre: Optional[View] = None, mul: Optional[View] = None, post: Optional[View] = None,
+                 post2: Optional[View] = None, flags: int = 0, out_nchw: Optional[torch.Tensor] = None) -> L.VamConv:
+    """Describe one problem.  ``inputs`` are concatenated along channels (virtually)."""
+    c = L.VamConv()
+    assert 1 <= len(inputs) <= L.VAM_MAX_SEG
+    in3 = isinstance(inputs[0], View3)
+    assert all(isinstance(v, View3) == in3 for v in inputs), "a conv problem reads either fp32 or bf16x3-plane segments"
+    if in3:
+        flags |= L.CONV_IN_BF3
+    if isinstance(out, View3):
+        assert out_nchw is None
+        flags |= L.CONV_OUT_BF3
+    B, H, W = inputs[0].B, inputs[0].H, inputs[0].W
+    cin = 0
+    for i, v in enumerate(inputs):
+        assert (v.B, v.H, v.W) == (B, H, W), "all input segments must share the spatial extent"
+        c.seg[i].ptr = v.ptr
+        c.seg[i].C = v.C
+        c.seg[i].ld = v.ld
+        cin += v.C
+    assert cin == pk.cin, f"conv expects {pk.cin} input channels, got {cin}"
+    c.n_seg = len(inputs)
+    c.B, c.H, c.W = B, H, W
+    c.kh, c.kw, c.stride, c.pad_y, c.pad_x = pk.kh, pk.kw, pk.stride, pk.pad_y, pk.pad_x
+    if pk.stride == 1:
+        Ho, Wo = H, W
+    else:
+        Ho = (H + 2 * pk.pad_y - pk.kh) // pk.stride + 1
+        Wo = (W + 2 * pk.pad_x - pk.kw) // pk.stride + 1
+    c.Ho, c.Wo = Ho, Wo
+    c.N = pk.n
+    c.wpack = pk.w.data_ptr()
+    c.bias = pk.b.data_ptr() if pk.b is not None else None
+    c.osy, c.osx, c.ooy, c.oox = pk.osy, pk.osx, pk.ooy, pk.oox
+    c.Cq = pk.ps2_cq
+    c.act = act
+    c.flags = flags | (L.CONV_PS2 if pk.ps2_cq else 0)
+    if out_nchw is not None:
+        assert out_nchw.is_contiguous()
+        c.flags |= L.CONV_OUT_NCHW
+        c.out = out_nchw.data_ptr()
+        c.Hf, c.Wf = out_nchw.shape[2], out_nchw.shape[3]
+        c.ldo = 0
+        cexp = pk.ps2_cq if pk.ps2_cq else pk.n
+        assert out_nchw.shape[0] == B and out_nchw.shape[1] == cexp
+    else:
+        c.out = out.ptr
+        c.ldo = out.ld
+        c.Hf, c.Wf = out.H, out.W
+        cexp = pk.ps2_cq if pk.ps2_cq else pk.n
+        assert out.B == B and out.C == cexp, f"output window has {out.C} channels, problem writes {cexp}"
+    if pk.ps2_cq:
+        assert (c.Hf, c.Wf) == (2 * Ho, 2 * Wo)
+    else:
+        assert (Ho - 1) * pk.osy + pk.ooy < c.Hf and (Wo - 1) * pk.osx + pk.oox < c.Wf
+    c.pre, c.mul, c.post, c.post2 = _aux(pre), _aux(mul), _aux(post), _aux(post2)
+    return c
+
+
+def conv_group(problems: Sequence[L.VamConv]):
+    lib = L.load()
+    s = stream_ptr()
+    for i in range(0, len(problems), L.VAM_MAX_GROUP):
+        chunk = problems[i:i + L.VAM_MAX_GROUP]
+        arr = (L.VamConv * len(chunk))(*chunk)
+        L.check(lib.vam_conv_group(arr, len(chunk), s), "vam_conv_group")
+
+
+# --------------------------------------------------------------------------- other ops
+def s2d_input(x: torch.Tensor) -> View:
+    B, C_, H, W = x.shape
+    assert C_ == 3 and x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    out = new_view(B, H // 2, W // 2, 16)
+    L.check(L.load().vam_s2d_input(x.data_ptr(), out.ptr, B, H, W, stream_ptr()), "vam_s2d_input")
+    return out
+
+
+def win_attention(qkv: View, out: View, table: torch.Tensor, C_: int, heads: int, ws: int, shift: int):
+    L.check(L.load().vam_win_attention(qkv.ptr, qkv.ld, out.ptr, out.ld, table.data_ptr(), qkv.B, qkv.H, qkv.W, C_, heads,
+                                       ws, shift, stream_ptr()), "vam_win_attention")
+
+
+def variance_mask(sigma: View, pr: float, mask: View, n_slice: int = 1, slice_C: Optional[int] = None,
+                  thr: Optional[torch.Tensor] = None):
+    """sigma/mask windows hold n_slice consecutive slices of slice_C channels each; one
+    quantile per (batch item, slice)."""
+    slice_C = slice_C or sigma.C // n_slice
+    assert slice_C * n_slice == sigma.C == mask.C
+    hw = sigma.H * sigma.W
+    L.check(L.load().vam_variance_mask(sigma.ptr, sigma.ld, hw * sigma.ld, slice_C, sigma.B, n_slice, hw, slice_C, float(pr),
+                                       mask.ptr, mask.ld, hw * mask.ld, slice_C,
+                                       thr.data_ptr() if thr is not None else None, stream_ptr()), "vam_variance_mask")
+
+
+@dataclass
+class IView:
+    """int32 NHWC channel window (symbols / table indexes)."""
+    buf: torch.Tensor   # [B,H,W,ld] int32
+    c0: int
+    C: int
+
+    @property
+    def ptr(self): return self.buf.data_ptr() + 4 * self.c0
+    @property
+    def ld(self): return self.buf.shape[3]
+
+    def window(self, c0, C_): return IView(self.buf, self.c0 + c0, C_)
+
+
+def new_iview(B, H, W, C_, device="cuda") -> IView:
+    return IView(torch.empty((B, H, W, C_), dtype=torch.int32, device=device), 0, C_)
+
+
+def gauss_tail(y: View, mu: View, sigma: View, *, y2: Optional[View] = None, mask: Optional[View] = None,
+               yhat: Optional[View] = None, lik: Optional[View] = None, sym=None,
+               log2sum: Optional[torch.Tensor] = None):
+    n_pix = y.n_pix
+    def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
+    if sym is None:
+        sym_ptr, sym_ld = None, 0
+    elif isinstance(sym, IView):
+        sym_ptr, sym_ld = sym.ptr, sym.ld
+    else:
+        sym_ptr, sym_ld = sym.data_ptr(), sym.shape[-1]
+    L.check(L.load().vam_gauss_tail(*p(y), *p(y2), *p(mu), *p(sigma), *p(mask), *p(yhat), *p(lik), sym_ptr, sym_ld,
+                                    log2sum.data_ptr() if log2sum is not None else None, y.H * y.W, n_pix, y.C,
+                                    stream_ptr()), "vam_gauss_tail")
+
+
+def build_indexes(sigma: View, table: torch.Tensor, mask: Optional[View] = None, out: Optional[IView] = None) -> torch.Tensor:
+    if out is None:
+        out = new_iview(sigma.B, sigma.H, sigma.W, sigma.C, sigma.buf.device)
+    L.check(L.load().vam_build_indexes(sigma.ptr, sigma.ld, mask.ptr if mask is not None else None,
+                                       mask.ld if mask is not None else 0, table.data_ptr(), table.numel(),
+                                       out.ptr, out.ld, sigma.n_pix, sigma.C, stream_ptr()), "vam_build_indexes")
+    return out.buf
+
+
+def dequantize(sym: IView, mu: Optional[View], out: View):
+    L.check(L.load().vam_dequantize(sym.ptr, sym.ld, mu.ptr if mu is not None else None, mu.ld if mu is not None else 0,
+                                    out.ptr, out.ld, out.n_pix, out.C, stream_ptr()), "vam_dequantize")
+
+
+def eb_forward(z: View, params: torch.Tensor, zhat: Optional[View], lik: Optional[View],
+               log2sum: Optional[torch.Tensor] = None, sym: Optional[IView] = None, noise: Optional[View] = None):
+    def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
+    L.check(L.load().vam_eb_forward_noise(z.ptr, z.ld, params.data_ptr(), z.C, *p(zhat), *p(lik), *p(sym),
+                                          log2sum.data_ptr() if log2sum is not None else None, z.H * z.W, z.n_pix,
+                                          *p(noise), stream_ptr()), "vam_eb_forward")
+
+
+def add(a: View, b: View, out: View):
+    L.check(L.load().vam_add(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.n_pix, a.C, stream_ptr()), "vam_add")
+
+
+# ---- REM fine-tune backward pieces (csrc/train.hip)
+def pack_conv_dgrad(weight: torch.Tensor) -> Packed:
+    """Weights of the data-gradient conv of a stride-1 ``nn.Conv2d`` (taps flipped, channel roles swapped)."""
+    n_out, c_in, kh, kw = weight.shape
+    w = pack_weights(weight, L.PACK_CONV_DGRAD, 0, kh, kw, n_out, c_in)
+    return Packed(w, None, kh, kw, n_out, c_in, 1, kh // 2, kw // 2)
+
+
+def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]) -> List[L.VamWgrad]:
+    """dw (OIHW) / db of a stride-1 conv whose input was the channel concat of ``x_segs``: one problem per segment."""
+    n, cin_total, kh, kw = dw.shape
+    assert dy.C == n and sum(v.C for v in x_segs) == cin_total and dw.is_contiguous() and kh == kw
+    out, off = [], 0
+    for v in x_segs:
+        assert (v.B, v.H, v.W) == (dy.B, dy.H, dy.W)
+        p = L.VamWgrad()
+        p.x, p.dy, p.dw = v.ptr, dy.ptr, dw.data_ptr()
+        p.db = db.data_ptr() if (db is not None and off == 0) else None
+        p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, v.B, v.H, v.W, kh, kw, v.C, n
+        p.cin_total, p.c_off = cin_total, off
+        out.append(p)
+        off += v.C
+    return out
+
+
+def wgrad_group(problems: Sequence[L.VamWgrad]):
+    lib = L.load()
+    for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
+        chunk = list(problems[i:i + L.VAM_MAX_WGRAD_GROUP])
+        arr = (L.VamWgrad * len(chunk))(*chunk)
+        L.check(lib.vam_conv_wgrad_group(arr, len(chunk), stream_ptr()), "vam_conv_wgrad_group")
+
+
+def conv_wgrad(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]):
+    wgrad_group(wgrad_problems(x_segs, dy, dw, db))
+
+
+def leaky_bwd(act: View, dy: View, dx: View):
+    L.check(L.load().vam_leaky_bwd(act.ptr, act.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, dx.n_pix, dx.C, stream_ptr()), "vam_leaky_bwd")
+
+
+def mul(a: View, b: View, out: View):
+    L.check(L.load().vam_mul(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, out.n_pix, out.C, stream_ptr()), "vam_mul")
+
+
+def gauss_train(y: View, mu: View, sigma: View, noise: View, *, y2: Optional[View] = None, mask: Optional[View] = None,
+                lik: Optional[View] = None, grad_lik: Optional[View] = None, dmu: Optional[View] = None,
+                dsigma: Optional[View] = None):
+    """Noisy-likelihood forward (``lik``) or backward (``grad_lik`` -> ``dmu``, ``dsigma``)."""
+    def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
+    L.check(L.load().vam_gauss_train(*p(y), *p(y2), *p(mu), *p(sigma), *p(mask), *p(noise), *p(grad_lik), *p(lik),
+                                     *p(dmu), *p(dsigma), y.n_pix, y.C, stream_ptr()), "vam_gauss_train")
+
+
+def memset_zero(t: torch.Tensor):
+    L.check(L.load().vam_memset_zero(t.data_ptr(), t.numel() * t.element_size(), stream_ptr()), "vam_memset_zero")
+
+
+def sqdiff_sum(a: torch.Tensor, b: torch.Tensor, acc: torch.Tensor):
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    L.check(L.load().vam_sqdiff_sum(a.data_ptr(), b.data_ptr(), a.numel(), acc.data_ptr(), stream_ptr()), "vam_sqdiff_sum")
+
+
+# --------------------------------------------------------------------------- graphs / profiling
+class Graph:
+    """hipGraph capture of a sequence of libvampic launches on the current stream."""
+
+    def __init__(self):
+        self.exec = C.c_void_p(None)
+
+    def capture(self, fn):
+        lib = L.load()
+        s = stream_ptr()
+        L.check(lib.vam_graph_begin(s), "vam_graph_begin")
+        try:
+            fn()
+        finally:
+            rc = lib.vam_graph_end(s, C.byref(self.exec))
+        L.check(rc, "vam_graph_end")
+
+    def launch(self):
+        L.check(L.load().vam_graph_launch(self.exec, stream_ptr()), "vam_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                L.load().vam_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+def prof_enable(on: bool):
+    L.check(L.load().vam_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    L.check(L.load().vam_prof_reset())
+
+
+def prof_read():
+    lib = L.load()
+    out = {}
+    for fam, name in enumerate(L.FAMILY_NAMES):
+        ms, n, fl, by = C.c_double(), C.c_long(), C.c_double(), C.c_double()
+        L.check(lib.vam_prof_read(fam, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+    return out

@@ -1,0 +1,154 @@
+"""Deterministic synthetic weights and inputs.
+
+There are no pretrained checkpoints offline (reference README.md:82 links Google
+Drive), so parity fixtures, tests and the benchmark all use weights drawn from a
+counter-style generator keyed by the *state_dict key name*: the same key gets the
+same tensor whether it is filled into the reference model (golden generation in
+the build container), the CPU oracle, or the HIP model on the GPU box.  Nothing
+but a seed travels.
+
+Scaling keeps activations O(1) through the GELU/GDN stacks and spreads the
+predicted scales over the reference's 0.11…256 scale table so that the variance
+mask, ``build_indexes`` and the likelihood see a realistic range (including
+negative raw scales, which the reference clamps at 0.11).
+"""
+from __future__ import annotations
+
+import math
+import re
+import zlib
+from typing import Dict, Mapping
+
+import torch
+
+_SKIP = ("pedestal", "bound", "target", "relative_position_index", "_offset",
+         "_quantized_cdf", "_cdf_length", "scale_table", "scale_bound")
+_DECONV = re.compile(r"^g_s\.\d+\.(1|3|6|8)\.weight$")
+# per-layer gains that keep the random-weight network in a sane numeric range
+_GAINS = [(re.compile(p), g) for p, g in (
+    (r"^cc_scale_transforms(_prog)?\.\d+\.8\.weight$", 1.5),
+    (r"^g_a\.\d+\.7\.weight$", 5.0),
+    (r"^g_s\.\d+\.1\.weight$", 0.06),
+    (r"^g_s\.\d+\.3\.weight$", 0.9),
+    (r"^g_s\.\d+\.6\.weight$", 0.4),
+    (r"^g_s\.\d+\.8\.weight$", 0.08),
+)]
+
+
+def _gen(name: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFFFFFF)
+    return g
+
+
+def _uniform(shape, g: torch.Generator) -> torch.Tensor:
+    """U[0,1) on a 2^-24 grid built from integer draws: int -> float conversion and the
+    scaling are exact, so the value is bit-identical on every host (unlike torch.randn /
+    torch.exp, whose vectorised CPU kernels differ by an ulp between AVX2 and AVX-512)."""
+    return torch.randint(0, 1 << 24, shape, generator=g, dtype=torch.int32).to(torch.float32) * (2.0 ** -24)
+
+
+def _normal(shape, g: torch.Generator) -> torch.Tensor:
+    """Unit-variance bell (Irwin-Hall of 4 uniforms), exact IEEE adds only."""
+    u = _uniform(shape, g) + _uniform(shape, g)
+    v = _uniform(shape, g) + _uniform(shape, g)
+    return ((u + v) - 2.0) * 1.7320508075688772
+
+
+def synth_tensor(name: str, like: torch.Tensor, seed: int = 0):
+    """Return the synthetic value for state_dict entry ``name`` (or None to keep
+    the module's own default, for derived buffers)."""
+    if any(name.endswith(s) for s in _SKIP) or not like.is_floating_point():
+        return None
+    shape = tuple(like.shape)
+    g = _gen(name, seed)
+    rn = lambda: _normal(shape, g)
+    ru = lambda: _uniform(shape, g)
+    leaf = name.rsplit(".", 1)[-1]
+    ped = (2.0 ** -18) ** 2
+    if leaf == "beta":
+        return torch.sqrt(0.8 + 0.4 * ru() + ped)      # sqrt is correctly rounded everywhere
+    if leaf == "gamma":
+        c = shape[0]
+        return torch.sqrt(0.1 * torch.eye(c) + 0.004 * ru() + ped)
+    if leaf == "relative_position_bias_table":
+        return 0.5 * rn()
+    if leaf == "quantiles":
+        q = ru()
+        out = torch.empty(shape)
+        out[..., 0] = -10.0 + q[..., 0]
+        out[..., 1] = 0.8 * q[..., 1] - 0.4
+        out[..., 2] = 10.0 + q[..., 2]
+        return out
+    if leaf.startswith("_matrix"):
+        filt = (1, 3, 3, 3, 3, 1)
+        i = int(leaf[len("_matrix"):])
+        scale = 10.0 ** (1 / 5)
+        init = math.log(math.expm1(1 / scale / filt[i + 1]))
+        return init + 0.3 * rn()
+    if leaf.startswith("_bias"):
+        return ru() - 0.5
+    if leaf.startswith("_factor"):
+        return 0.3 * rn()
+    if leaf == "bias":
+        b = 0.05 * rn()
+        if re.match(r"^cc_scale_transforms(_prog)?\.\d+\.8\.bias$", name):
+            b = b + 1.5
+        elif re.match(r"^g_s\.\d+\.8\.bias$", name):
+            b = b + 0.5
+        return b
+    if leaf == "weight":
+        if len(shape) == 4:
+            if _DECONV.match(name):
+                fan = shape[0] * shape[2] * shape[3] / 4.0
+            else:
+                fan = shape[1] * shape[2] * shape[3]
+            gain = 1.3
+            for pat, gv in _GAINS:
+                if pat.match(name):
+                    gain = gv
+                    break
+            return rn() * (gain / math.sqrt(fan))
+        if len(shape) == 2:
+            return rn() * (1.0 / math.sqrt(shape[1]))
+    return 0.1 * rn()
+
+
+def normal(shape, seed: int, scale: float = 1.0) -> torch.Tensor:
+    """Host-independent test tensor: unit-variance bell times ``scale``."""
+    return _normal(tuple(shape), _gen("normal:" + "x".join(map(str, shape)), seed)) * scale
+
+
+def uniform(shape, seed: int) -> torch.Tensor:
+    return _uniform(tuple(shape), _gen("uniform:" + "x".join(map(str, shape)), seed))
+
+
+def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Fill every entry of ``template`` (name -> tensor giving shape/dtype)."""
+    out = {}
+    for k, v in template.items():
+        t = synth_tensor(k, v, seed)
+        out[k] = v.detach().clone().cpu() if t is None else t.to(v.dtype)
+    return out
+
+
+def synth_image(batch: int, height: int, width: int, seed: int = 0) -> torch.Tensor:
+    """x ~ U[0,1) fp32 NCHW, smooth-ish (low-pass of noise + noise) so that the
+    synthesis transform sees image-like statistics."""
+    g = _gen(f"image:{batch}x{height}x{width}", seed)
+    return _uniform((batch, 3, height, width), g)
+
+
+def synth_sigma(n_seg: int, n: int, seed: int = 0) -> torch.Tensor:
+    """Operator-level scale inputs for the mask kernel: log-uniform-like over
+    [2^-5, 2^9) (exponent uniform, mantissa uniform — assembled from integer bits, so
+    bit-identical on every host) with ~1 % exact ties and ~0.1 % negatives."""
+    g = _gen(f"sigma:{n_seg}x{n}", seed)
+    expo = torch.randint(122, 136, (n_seg, n), generator=g, dtype=torch.int32)       # 2^-5 .. 2^8
+    mant = torch.randint(0, 1 << 23, (n_seg, n), generator=g, dtype=torch.int32)
+    s = ((expo << 23) | mant).view(torch.float32)
+    tie = torch.randint(0, 100, (n_seg, n), generator=g) == 0
+    src = torch.randint(0, n, (n_seg, n), generator=g)
+    s = torch.where(tie, torch.gather(s, 1, src), s)
+    neg = torch.randint(0, 1000, (n_seg, n), generator=g) == 0
+    return torch.where(neg, -s, s).contiguous()
