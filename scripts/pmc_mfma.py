@@ -45,9 +45,10 @@ def main():
         clk = gui / a["_ns"] if a["_ns"] else 0.0
         util = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else 0.0
         wc = a.get("SQ_WAVE_CYCLES", 0.0) or 1.0
-        # last template argument of conv_igemm_kernel: 1 = bf16 split operands (1024 FLOP/clk/SIMD, 6 MFMA FLOP per
+        # MODE template argument (6th) of conv_igemm_kernel: 1 = bf16 split operands (1024 FLOP/clk/SIMD, 6 MFMA FLOP per
         # algorithmic FLOP), 0 = fp32 operands (64 FLOP/clk/SIMD)
-        split = k.rstrip(">").endswith(", 1")
+        targs = k[k.find("<") + 1:k.rfind(">")].split(",") if "<" in k else []
+        split = "conv_igemm_kernel" in k and len(targs) >= 6 and targs[5].strip() == "1"
         tf = util * 1024 * (1024 if split else 64) * clk / 1e3
         tf_eq = tf / 6.0 if split else tf
         ldsr = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"] if a.get("SQ_LDS_IDX_ACTIVE") else float("nan")
