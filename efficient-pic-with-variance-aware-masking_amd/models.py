@@ -276,6 +276,10 @@ class VarianceMaskingPIC(CompressionModel):
         pr = quality
         if mask_pol == "two-levels" and quality != 0:
             pr = 10                                   # channel_mask.py:152-153: all ones unless pr == 0
+        nb = _max_images_per_plan(x)
+        if x.shape[0] > nb:                            # tensors of one plan are addressed with 32-bit byte offsets
+            return _cat_outputs([self.forward_single_quality(x[i:i + nb], quality, mask_pol, False, True)
+                                 for i in range(0, x.shape[0], nb)])
         plan = self._plan(x, base_only=(quality == 0))
         return plan.execute(x, pr, None, self.use_graph, clone)
 
@@ -458,6 +462,11 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         self._check_config()
         if not self.mu_std:
             raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
+        nb = _max_images_per_plan(x)
+        if x.shape[0] > nb:                            # tensors of one plan are addressed with 32-bit byte offsets
+            return _cat_outputs([self.forward(x[i:i + nb], mask_pol, quality, False,
+                                              None if checkpoint_ref is None else checkpoint_ref[i:i + nb], True)
+                                 for i in range(0, x.shape[0], nb)])
         rem_idx = self._rem_choice(quality, checkpoint_ref) if quality != 0 else None
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
         plan = self._plan(x, base_only=(quality == 0), rem_idx=rem_idx)
@@ -540,6 +549,32 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
 
 
 # ----------------------------------------------------------------------------- the fused plan
+# Largest tensor of a plan: the 192-channel feature map at half resolution (and the 576-channel qkv at quarter
+# resolution, smaller).  The kernels address a tensor with 32-bit BYTE offsets, so one plan holds at most
+# 2^31 / (192 ch * 4 B) / (1/4) pixels of input; larger batches run as several plans over sub-batches.
+MAX_PLAN_PIXELS = int((2 ** 31 - 2 ** 20) // (192 * 4) * 4)
+
+
+def _max_images_per_plan(x) -> int:
+    return max(1, MAX_PLAN_PIXELS // (x.shape[2] * x.shape[3]))
+
+
+def _cat_outputs(outs):
+    """Concatenate per-sub-batch result dicts along the batch dimension (every image is an independent unit)."""
+    def cat(vals):
+        v0 = vals[0]
+        if isinstance(v0, dict):
+            return {k: cat([v[k] for v in vals]) for k in v0}
+        if isinstance(v0, (list, tuple)):
+            return type(v0)(cat([v[i] for v in vals]) for i in range(len(v0)))
+        if torch.is_tensor(v0):
+            if v0.dim() == 2 and v0.dtype == torch.float64:          # log2_likelihood_sum [2, B]
+                return torch.cat(vals, dim=1)
+            return torch.cat(vals, dim=0)
+        return v0
+    return cat(outs)
+
+
 def _slice_stack_heads(plan, m, means_h, scales_h, which):
     """Hyperprior part of the first layer of every slice stack (engine.lower_stack_heads): base stacks read the first
     ``d`` channels of the hyper tensors, progressive ones the second (pic.py:528-529,598-599); the LRP stacks share the

@@ -148,3 +148,22 @@ def test_module_surface_of_the_harness(gpu_model):
                  "multiple_encoder", "multiple_decoder", "multiple_hyperprior", "delta_encode", "total_mu_rep",
                  "mu_std", "check_levels", "num_rems", "enable_rem"):
         assert hasattr(net, name), name
+
+
+def test_large_batches_run_as_sub_batches(gpu_model, monkeypatch):
+    """A plan addresses its tensors with 32-bit byte offsets; bigger batches are split into sub-batches (images are
+    independent units).  With the limit lowered artificially the split result must equal the one-plan result bit for bit."""
+    import sys
+    M = sys.modules["vampic.models"]          # (the attribute vampic.models is the reference's `models` dict)
+    net, _ = gpu_model
+    x = vampic.synth.synth_image(5, 64, 64, seed=11).cuda()
+    with torch.no_grad():
+        whole = net.forward_single_quality(x, 2.5)
+        monkeypatch.setattr(M, "MAX_PLAN_PIXELS", 2 * 64 * 64)
+        parts = net.forward_single_quality(x, 2.5)
+    for k in ("x_hat", "y_hat", "mask"):
+        assert torch.equal(whole[k], parts[k]), k
+    assert torch.equal(whole["likelihoods"]["y"], parts["likelihoods"]["y"])
+    # the per-image rate sums are double-precision atomics: same terms, order not fixed
+    a, b = whole["log2_likelihood_sum"], parts["log2_likelihood_sum"]
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())
