@@ -15,6 +15,8 @@
 
 namespace vam {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // pairs of fp32: v_pk_fma_f32 does two fmas per instruction
+
 template <int WS, int HD>
 __global__ __launch_bounds__(64) void win_attn_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                       float* __restrict__ out, int ld_out,
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const float* __restrict__ 
                                                       int C, int heads, int shift, float scale) {
   constexpr int N = WS * WS;        // tokens per window
   constexpr int HPW = 64 / N;       // heads per wave
-  constexpr int LD = HD + 1;
+  constexpr int LD = HD + 4;       // rows stay 16-byte aligned: K / V rows are read as wave-broadcast ds_read_b128
   __shared__ float sK[HPW * N * LD];
   __shared__ float sV[HPW * N * LD];
 
@@ -73,9 +75,14 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const float* __restrict__ 
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const float* kr = sK + (hs * N + u) * LD;
-    float acc = 0.f;
+    // even / odd head-dim elements accumulate in the two halves of a packed fma, summed at the end
+    f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
-    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[d], acc);
+    for (int d = 0; d < HD; d += 2) {
+      const f32x2 qq = {q[d], q[d + 1]}, kk = {kr[d], kr[d + 1]};
+      acc2 = __builtin_elementwise_fma(qq, kk, acc2);
+    }
+    float acc = acc2.x + acc2.y;
     const int ui = u / WS, uj = u % WS;
     const int ridx = (ti - ui + WS - 1) * (2 * WS - 1) + (tj - uj + WS - 1);
     acc = acc + table[ridx * heads + head];
@@ -91,16 +98,23 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const float* __restrict__ 
     sum += s[u];
   }
   const float inv = 1.0f / sum;
-  float o[HD];
+  f32x2 o2[HD / 2];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int d = 0; d < HD / 2; ++d) o2[d] = f32x2{0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const float* vr = sV + (hs * N + u) * LD;
     const float p = s[u] * inv;
+    const f32x2 pp = {p, p};
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = fmaf(p, vr[d], o[d]);
+    for (int d = 0; d < HD / 2; ++d) {
+      const f32x2 vv = {vr[2 * d], vr[2 * d + 1]};
+      o2[d] = __builtin_elementwise_fma(pp, vv, o2[d]);
+    }
   }
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD / 2; ++d) { o[2 * d] = o2[d].x; o[2 * d + 1] = o2[d].y; }
   float* dst = out + pix * ld_out + head * HD;
 #pragma unroll
   for (int d = 0; d < HD; d += 4)
