@@ -514,7 +514,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + j * 32 * RS + pl * 16 + rd1[ks]);
-        __builtin_amdgcn_s_setprio(1);               // matrix phase: do not let the partner wave's staging VALU starve the issue
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -527,7 +526,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
           }
-        __builtin_amdgcn_s_setprio(0);
       }
     };
     if constexpr (NBUF == 2) {
