@@ -23,6 +23,8 @@ PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD = range(5)
 # enum vam_family
 FAM_CONV, FAM_ATTN, FAM_MASK, FAM_TAIL, FAM_MISC = range(5)
 FAMILY_NAMES = ("conv_igemm", "win_attn", "variance_mask", "gauss_tail", "misc")
+# launch classes of the event profiler (vam_prof_set_class): which part of the path a conv launch belongs to
+PROF_CLASSES = ("other", "g_a", "g_s", "hyperprior", "stack_heads", "slice_chain", "lrp_prog", "rem")
 
 
 class VamSeg(C.Structure):
@@ -112,6 +114,8 @@ _SIGNATURES = {
     "vam_prof_enable": (C.c_int, [C.c_int]),
     "vam_prof_reset": (C.c_int, []),
     "vam_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vam_prof_set_class": (C.c_int, [C.c_int]),
+    "vam_prof_read_class": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -30,7 +30,10 @@ class Tables:
     def of(model) -> "Tables":
         if model._quantized_cdf.numel() == 0:
             raise ValueError("Uninitialized CDFs. Run update() first")
-        key = (model._quantized_cdf.data_ptr(), model._quantized_cdf._version, model._offset._version)
+        # _tables_generation is bumped by update() / load_state_dict(): a re-built table can land at the address (and
+        # version) of the one it replaced, so pointers alone do not identify it
+        key = (getattr(model, "_tables_generation", 0), model._quantized_cdf.data_ptr(), model._quantized_cdf._version,
+               model._offset._version, tuple(model._quantized_cdf.shape))
         if getattr(model, "_tables_key", None) != key:
             t = Tables(np.ascontiguousarray(model._quantized_cdf.detach().cpu().numpy(), dtype=np.int32),
                        np.ascontiguousarray(model._cdf_length.detach().cpu().reshape(-1).numpy(), dtype=np.int32),

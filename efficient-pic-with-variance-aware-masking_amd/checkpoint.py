@@ -23,10 +23,23 @@ def save_checkpoint(state: dict, is_best: bool, last_pth: str, very_best: str):
     torch.save(state, very_best if is_best else last_pth)
 
 
-def load_checkpoint(path: str, model=None, map_location="cpu", strict: bool = True) -> dict:
+def load_checkpoint(path: str, model=None, map_location="cpu", strict: bool = True, allow_pickle: bool = False) -> dict:
     """``torch.load`` + ``model.load_state_dict(checkpoint["state_dict"])`` as demo.py:46-52 / train.py:96-108 do
-    (the REM model's own ``load_state_dict`` takes care of ``post_latent.*``)."""
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    (the REM model's own ``load_state_dict`` takes care of ``post_latent.*``).
+
+    The reference's checkpoints carry ``"args": argparse.Namespace`` beside the tensors (train.py:371-383), which
+    ``torch.load`` can only restore by unpickling.  The safe loader is tried first with ``argparse.Namespace``
+    allow-listed; full unpickling (arbitrary code execution from an untrusted file) happens only on the explicit
+    ``allow_pickle=True``."""
+    import argparse
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ck = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:                                  # noqa: BLE001 - any unpickling restriction
+        if not allow_pickle:
+            raise RuntimeError(f"{path} holds objects the safe loader refuses ({type(e).__name__}: {e}); pass "
+                               "allow_pickle=True only for checkpoints you trust") from e
+        ck = torch.load(path, map_location=map_location, weights_only=False)
     if model is not None:
         model.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck, strict=strict)
     return ck

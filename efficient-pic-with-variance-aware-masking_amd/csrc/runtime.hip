@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
   hipEvent_t a, b;
   int family;
+  int cls;
 };
 struct ProfState {
   bool on = false;
@@ -26,6 +27,12 @@ struct ProfState {
   long launches[VAM_FAM_COUNT] = {0};
   double flops[VAM_FAM_COUNT] = {0};
   double bytes[VAM_FAM_COUNT] = {0};
+  // the same sums per caller-defined launch class (vam_prof_set_class): which part of the model a launch belongs to
+  int cur_class = 0;
+  double c_ms[VAM_PROF_CLASSES] = {0};
+  long c_launches[VAM_PROF_CLASSES] = {0};
+  double c_flops[VAM_PROF_CLASSES] = {0};
+  double c_bytes[VAM_PROF_CLASSES] = {0};
   std::mutex mu;
 };
 static ProfState g_prof;
@@ -36,6 +43,7 @@ ProfScope::ProfScope(int fam, hipStream_t s, double fl, double by)
   std::lock_guard<std::mutex> lk(g_prof.mu);
   ProfRec r;
   r.family = fam;
+  r.cls = g_prof.cur_class;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   (void)hipEventRecord(r.a, s);
   g_prof.recs.push_back(r);
@@ -43,6 +51,11 @@ ProfScope::ProfScope(int fam, hipStream_t s, double fl, double by)
   g_prof.launches[fam] += 1;
   g_prof.flops[fam] += fl;
   g_prof.bytes[fam] += by;
+  if (fam == VAM_FAM_CONV) {
+    g_prof.c_launches[r.cls] += 1;
+    g_prof.c_flops[r.cls] += fl;
+    g_prof.c_bytes[r.cls] += by;
+  }
   active = true;
 }
 
@@ -56,7 +69,10 @@ static int prof_drain() {
   for (auto& r : g_prof.recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) g_prof.ms[r.family] += ms;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_prof.ms[r.family] += ms;
+      if (r.family == VAM_FAM_CONV) g_prof.c_ms[r.cls] += ms;
+    }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
@@ -136,6 +152,30 @@ int vam_prof_reset(void) {
     g_prof.flops[i] = 0;
     g_prof.bytes[i] = 0;
   }
+  for (int i = 0; i < VAM_PROF_CLASSES; ++i) {
+    g_prof.c_ms[i] = 0;
+    g_prof.c_launches[i] = 0;
+    g_prof.c_flops[i] = 0;
+    g_prof.c_bytes[i] = 0;
+  }
+  return VAM_OK;
+}
+
+int vam_prof_set_class(int cls) {
+  VAM_REQUIRE(cls >= 0 && cls < VAM_PROF_CLASSES, "vam_prof_set_class: class %d outside 0..%d", cls, VAM_PROF_CLASSES - 1);
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.cur_class = cls;
+  return VAM_OK;
+}
+
+int vam_prof_read_class(int cls, double* ms, long* launches, double* flops, double* bytes) {
+  VAM_REQUIRE(cls >= 0 && cls < VAM_PROF_CLASSES, "vam_prof_read_class: class %d outside 0..%d", cls, VAM_PROF_CLASSES - 1);
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  prof_drain();
+  if (ms) *ms = g_prof.c_ms[cls];
+  if (launches) *launches = g_prof.c_launches[cls];
+  if (flops) *flops = g_prof.c_flops[cls];
+  if (bytes) *bytes = g_prof.c_bytes[cls];
   return VAM_OK;
 }
 

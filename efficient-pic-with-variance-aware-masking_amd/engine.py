@@ -37,6 +37,8 @@ class Plan:
         self.meta: List[dict] = []            # one entry per step: what it is and its algorithmic FLOP
         self.branch_of: List[int] = []        # stream branch of each step (0 = the caller's stream)
         self.cur_branch = 0
+        self.class_of: List[int] = []         # launch class of each step (event profiler: L.PROF_CLASSES)
+        self.cur_class = 0
         self.n_events = 0
         self._side: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -69,6 +71,7 @@ class Plan:
             self.meta.append({"kind": "conv", "flops": fl, "desc": f"{n}x[{sum(c0.seg[k].C for k in range(c0.n_seg))}->{c0.N} "
                               f"k{c0.kh}x{c0.kw} s{c0.stride} P={c0.B * c0.Ho * c0.Wo}]"})
             self.branch_of.append(self.cur_branch)
+            self.class_of.append(self.cur_class)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
     def wgrad(self, problems: Sequence[L.VamWgrad]):
@@ -83,12 +86,14 @@ class Plan:
             self.flops += fl
             self.meta.append({"kind": "wgrad", "flops": fl, "desc": f"{n}x wgrad [{chunk[0].C}->{chunk[0].N} k{chunk[0].kh}]"})
             self.branch_of.append(self.cur_branch)
+            self.class_of.append(self.cur_class)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_wgrad_group(arr, n, ops.stream_ptr()),
                                                            "vam_conv_wgrad_group"))
 
     def call(self, fn: Callable[[], None], desc: str = "op"):
         self.meta.append({"kind": "op", "flops": 0.0, "desc": desc})
         self.branch_of.append(self.cur_branch)
+        self.class_of.append(self.cur_class)
         self.steps.append(fn)
 
     # ---- concurrency: independent chains are recorded on different branches (HIP streams) and
@@ -96,18 +101,24 @@ class Plan:
     def branch(self, b: int):
         self.cur_branch = b
 
+    def set_class(self, name: str):
+        """Launch class of the steps recorded from here on (what the event profiler sums convolution time by)."""
+        self.cur_class = L.PROF_CLASSES.index(name)
+
     def record(self) -> int:
         """Mark "everything recorded so far on the current branch is done"; returns an event id."""
         idx = self.n_events
         self.n_events += 1
         self.meta.append({"kind": "event", "flops": 0.0, "desc": f"record {idx}"})
         self.branch_of.append(self.cur_branch)
+        self.class_of.append(self.cur_class)
         self.steps.append(("rec", idx))
         return idx
 
     def wait(self, idx: int):
         self.meta.append({"kind": "event", "flops": 0.0, "desc": f"wait {idx}"})
         self.branch_of.append(self.cur_branch)
+        self.class_of.append(self.cur_class)
         self.steps.append(("wait", idx))
 
     def profile(self, reps: int = 3):
@@ -129,8 +140,11 @@ class Plan:
     # ---- execution
     def run(self):
         main = torch.cuda.current_stream(self.device)
+        prof = ops.prof_on()
         if self.n_events == 0:
-            for s in self.steps:
+            for c, s in zip(self.class_of, self.steps):
+                if prof:
+                    ops.prof_set_class(c)
                 s()
             return
         streams = {0: main}
@@ -142,7 +156,9 @@ class Plan:
         events = [torch.cuda.Event() for _ in range(self.n_events)]
         cur = 0
         try:
-            for b, s in zip(self.branch_of, self.steps):
+            for b, c, s in zip(self.branch_of, self.class_of, self.steps):
+                if prof and not isinstance(s, tuple):
+                    ops.prof_set_class(c)
                 if b != cur:
                     torch.cuda.set_stream(streams[b])
                     cur = b

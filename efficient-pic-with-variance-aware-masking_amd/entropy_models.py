@@ -220,6 +220,7 @@ class EntropyBottleneck(EntropyModel):
         tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
+        object.__setattr__(self, "_tables_generation", getattr(self, "_tables_generation", 0) + 1)   # bitstream.Tables.of
         return True
 
     @staticmethod
@@ -294,6 +295,7 @@ class GaussianConditional(EntropyModel):
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
         self._offset = (-pmf_center).to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
+        object.__setattr__(self, "_tables_generation", getattr(self, "_tables_generation", 0) + 1)   # bitstream.Tables.of
         return True
 
     def forward(self, inputs, scales, means=None, training=None, mask=None):

@@ -73,6 +73,11 @@ def rems_quality_list(check_levels: Sequence[float], check_levels_np: Sequence[i
     return qs
 
 
+def _dist_backend() -> Optional[str]:
+    import torch.distributed as dist
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
 def finetune_step(model, criterion, batch: torch.Tensor, optimizer, quality: float, check_levels: Sequence[float],
                   clip_max_norm: float = 1.0, noise=None, fused: bool = True) -> dict:
     """One optimisation step on this rank's shard of the batch (training/step.py:56-95).  ``fused``: the
@@ -88,7 +93,7 @@ def finetune_step(model, criterion, batch: torch.Tensor, optimizer, quality: flo
         out = model.forward_single_quality(batch, quality=quality, training=True, checkpoint_ref=ck, noise=noise)
     crit = criterion(out, batch)
     crit["loss"].backward()
-    sharding.all_reduce_gradients(p for p in model.parameters() if p.requires_grad)
+    sharding.all_reduce_gradients([p for p in model.parameters() if p.requires_grad])   # rank-invariant bucket
     if clip_max_norm > 0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
     optimizer.step()
@@ -105,7 +110,10 @@ def train_one_epoch(model, criterion, train_dataloader: Iterable[torch.Tensor], 
     n = 0
     for d in train_dataloader:
         d = d.to(device)
-        q = list_quality[rng.randint(0, len(list_quality) - 1)]
+        # one quality per step for the WHOLE job: rank 0 draws, every rank uses it (the quality selects which REM
+        # trains; ranks drawing independently would average gradients of different REMs)
+        red_dev = device if (_dist_backend() == "nccl") else "cpu"
+        q = list_quality[sharding.broadcast_choice(len(list_quality), rng, red_dev)]
         crit = finetune_step(model, criterion, d, optimizer, q, rems, clip_max_norm)
         for k in tot:
             tot[k] += float(crit[k].detach().mean())

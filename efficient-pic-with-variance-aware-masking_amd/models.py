@@ -189,11 +189,14 @@ class VarianceMaskingPIC(CompressionModel):
                             ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
         self._plans.clear()
         self._dec_plans.clear()
+        for em in (self.gaussian_conditional, self.entropy_bottleneck):      # loaded CDF tables replace the cached host copies
+            object.__setattr__(em, "_tables_generation", getattr(em, "_tables_generation", 0) + 1)
         return nn.Module.load_state_dict(self, state_dict, strict=strict)
 
     def _apply(self, fn, *a, **k):
         self._plans.clear()
         self._dec_plans.clear()
+        self.__dict__.pop("_sig_params", None)
         return super()._apply(fn, *a, **k)
 
     def __deepcopy__(self, memo):
@@ -201,6 +204,7 @@ class VarianceMaskingPIC(CompressionModel):
         import copy
         held = self._plans, self._dec_plans
         self._plans, self._dec_plans = {}, {}
+        self.__dict__.pop("_sig_params", None)
         try:
             new = self.__class__.__new__(self.__class__)
             memo[id(self)] = new
@@ -258,10 +262,27 @@ class VarianceMaskingPIC(CompressionModel):
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
+        wsig = self._weights_sig()
+        if p is not None and p.wsig != wsig:
+            p = None                # a parameter was edited in place (param.data.copy_, nn.init, optimizer step)
         if p is None:
             p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck)
+            p.wsig = wsig
             self._plans[key] = p
         return p
+
+    def _weights_sig(self):
+        """(_version, data_ptr) of every parameter the plans pack ONCE (everything except ``post_latent``, whose
+        training plans re-pack in place every step and whose eval plans carry ``rem_sig``): a plan built before an
+        in-place edit of a weight must not be replayed."""
+        ps = self.__dict__.get("_sig_params")
+        if ps is None:
+            ps = [p for n, p in self.named_parameters() if not n.startswith("post_latent.")]
+            self.__dict__["_sig_params"] = ps
+        h = 0
+        for p in ps:
+            h = (h * 1000003 + p._version * 31 + (p.data_ptr() >> 4)) & 0xFFFFFFFFFFFFFFF
+        return h
 
     def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, clone=True):
         """models/pic.py:497-666 (eval).  Returns the reference's dict; tensors are NCHW-shaped."""
@@ -367,8 +388,12 @@ class VarianceMaskingPIC(CompressionModel):
         dp = self._dec_plans.get(key)
         if dp is not None and rem_idx is not None and dp.rem_sig != _version_sig(self.post_latent[rem_idx]):
             dp = None               # REM fine-tuned since the plan packed its weights
+        wsig = self._weights_sig()
+        if dp is not None and dp.wsig != wsig:
+            dp = None               # a weight was edited in place since the plan packed it
         if dp is None:
             dp = _DecPlan(self, B, hz, wz, base_only, rem_idx, dev)
+            dp.wsig = wsig
             dp.rem_sig = _version_sig(self.post_latent[rem_idx]) if rem_idx is not None else None
             self._dec_plans[key] = dp
         pr = 10 if (mask_pol == "two-levels" and quality != 0) else quality
@@ -608,10 +633,16 @@ class _RemTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, lik_y, use_graph, *params):
         ctx.plan, ctx.use_graph = plan, use_graph
+        ctx.generation = plan.generation      # the tape lives in the plan's buffers: it belongs to ONE execute()
         return lik_y.clone()
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError(
+                "the training plan for this shape ran again before this backward(): its tape (activations, noise, "
+                "mask) now belongs to the later forward.  Call loss.backward() before the next training forward of "
+                "the same shape (gradient accumulation: backward after every forward).")
         grads = ctx.plan.backward(g, ctx.use_graph)
         return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[3:]))
 
@@ -627,6 +658,7 @@ class _FsqPlan:
         self.symbols = symbols
         self.train = train          # additive-noise likelihoods (+ taped REM and a backward plan when rem_idx is set)
         self.bwd = None
+        self.generation = 0         # bumped by every execute(): which forward the training tape belongs to
         self.pr = 0.0
         self.graphs: Dict[float, ops.Graph] = {}
         self.stream = None
@@ -647,10 +679,12 @@ class _FsqPlan:
         plan.call(lambda: L.check(L.load().vam_s2d_input(self.x_in.data_ptr(), x_s2d.ptr, B, H, W, ops.stream_ptr()),
                                   "vam_s2d_input"))
         y = self.y = plan.buf(B, h, w, 2 * d)
+        plan.set_class("g_a")
         E.lower_g_a(plan, [m.g_a[0], m.g_a[1]], x_s2d, [y.window(0, d), y.window(d, d)])
 
         # ---- hyperprior                                                            pic.py:278-298
         z = plan.buf(B, h // 4, w // 4, m.N)
+        plan.set_class("hyperprior")
         E.lower_stacks(plan, [m.h_a], [[y]], [z])
         self.z_hat = plan.buf(B, h // 4, w // 4, m.N)
         self.z_lik = plan.buf(B, h // 4, w // 4, m.N)
@@ -683,7 +717,9 @@ class _FsqPlan:
         sl = lambda v, i, n=1: v.window(i * C, n * C)
         mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
         hyper_done = plan.record() if not base_only else None
+        plan.set_class("stack_heads")
         heads = _slice_stack_heads(plan, m, means_h, scales_h, "base")     # hyperprior part of every first layer, up front
+        plan.set_class("slice_chain")
 
         def base_group(idx: List[int]):
             sup = [sl(yb, 0, min(m.max_support_slices, idx[0]))] if idx[0] > 0 else []
@@ -717,6 +753,7 @@ class _FsqPlan:
 
         if base_only:
             if not symbols:                              # compress() does not decode (pic.py:671-860)
+                plan.set_class("g_s")
                 E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
             return
 
@@ -731,7 +768,9 @@ class _FsqPlan:
         # (pic.py:586-612), so it runs on a second HIP stream concurrently with base slices > j.
         plan.branch(1)
         plan.wait(hyper_done)
+        plan.set_class("stack_heads")
         heads.update(_slice_stack_heads(plan, m, means_h, scales_h, "prog"))   # on the chain's stream, beside base slice 0
+        plan.set_class("slice_chain")
         for j in range(ns):
             plan.wait(base_done[j])
             s = min(sp, j)
@@ -748,6 +787,7 @@ class _FsqPlan:
 
         mu_f, std_f = self.mu_p, self.std_p
         if rem_idx is not None:                                                       # rem_pic.py:363-377
+            plan.set_class("rem")
             self.ck = plan.buf(B, h, w, d)
             if own_ck:
                 # y_hat at the check level from the SAME front end (everything up to here is quality independent;
@@ -777,6 +817,7 @@ class _FsqPlan:
                 self.rem_sig = _version_sig(m.post_latent[rem_idx])
                 E.lower_rem_blocks(plan, mods, *rem_io)
         self.mu_f, self.std_f = mu_f, std_f
+        plan.set_class("lrp_prog")
         self.mask = plan.buf(B, h, w, d)
         self.thr = torch.empty((B * ns,), **f32)
         plan.keep.append(self.thr)
@@ -811,6 +852,7 @@ class _FsqPlan:
                        [sl(yp, j) for j in range(ns)],
                        [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
         if not symbols:
+            plan.set_class("g_s")
             E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
 
     # -------------------------------------------------------------------------------------------
@@ -851,6 +893,7 @@ class _FsqPlan:
         """Run the plan on the model's own HIP stream (hipGraph capture is not allowed on the
         legacy default stream), ordered after / before the caller's current stream."""
         self.pr = float(pr)
+        self.generation += 1
         self.ck_pr = float(ck_pr) if ck_pr is not None else 0.0
         if self.train and self.rem_idx is not None:
             sig = tuple(p.data_ptr() for p in self.rem_params)

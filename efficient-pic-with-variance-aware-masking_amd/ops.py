@@ -485,8 +485,33 @@ class Graph:
             pass
 
 
+_PROF_ON = False
+
+
 def prof_enable(on: bool):
+    global _PROF_ON
+    _PROF_ON = bool(on)
     L.check(L.load().vam_prof_enable(1 if on else 0))
+
+
+def prof_on() -> bool:
+    return _PROF_ON
+
+
+def prof_set_class(name_or_idx):
+    """Launch class of the convolution launches that follow (event profiler only; see L.PROF_CLASSES)."""
+    i = L.PROF_CLASSES.index(name_or_idx) if isinstance(name_or_idx, str) else int(name_or_idx)
+    L.check(L.load().vam_prof_set_class(i), "vam_prof_set_class")
+
+
+def prof_read_classes():
+    lib = L.load()
+    out = {}
+    for i, name in enumerate(L.PROF_CLASSES):
+        ms, n, fl, by = C.c_double(), C.c_long(), C.c_double(), C.c_double()
+        L.check(lib.vam_prof_read_class(i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+    return out
 
 
 def prof_reset():

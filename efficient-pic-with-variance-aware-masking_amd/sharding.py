@@ -44,19 +44,53 @@ def whole_job_megapixels_per_s(images_per_rank: int, height: int, width: int, st
 
 def all_reduce_gradients(params) -> int:
     """Average the gradients of ``params`` over the ranks with ONE collective on a flat bucket (the fine-tune
-    step's only exchange: BASELINE north_star "RCCL all-reduce over xGMI on the gradients only").  Returns the
-    number of bytes reduced (0 when not distributed)."""
+    step's only exchange: BASELINE north_star "RCCL all-reduce over xGMI on the gradients only").
+
+    The bucket layout is RANK-INVARIANT: it spans every parameter handed in (the caller passes the
+    ``requires_grad`` set, which is the same on all ranks), with zeros where this rank produced no gradient, plus
+    one presence word per parameter.  So every rank always enters the collective, with the same element count,
+    whatever subset of the parameters its step touched — a rank whose step used another REM (or none) can neither
+    shift another rank's gradients onto the wrong parameters nor leave the others waiting in the all-reduce.
+    A parameter that received a gradient on no rank keeps ``grad = None`` (the optimiser then skips it, as in a
+    single-process run).  Returns the number of bytes reduced (0 when not distributed)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = list(params)
+    if not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= dist.get_world_size()
+    dev, dt = params[0].device, params[0].dtype
+    n_el = sum(p.numel() for p in params)
+    flat = torch.zeros(n_el + len(params), dtype=dt, device=dev)
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    for i, p in enumerate(params):
+        if p.grad is not None:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            flat[n_el + i] = 1.0
+        off += p.numel()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    present = flat[n_el:].tolist()
+    flat[:n_el] /= dist.get_world_size()
+    off = 0
+    for i, p in enumerate(params):
+        if present[i] > 0:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+        off += p.numel()
     return flat.numel() * flat.element_size()
+
+
+def broadcast_choice(n_choices: int, rng, device="cpu") -> int:
+    """An index in [0, n_choices) drawn by rank 0's ``rng`` and shared with every rank: per-step random choices
+    that select WHICH parameters train (the sampled quality picks the REM, training/step.py:62-64) must agree
+    across ranks, or the gradient bucket would mix different modules' gradients."""
+    import torch.distributed as dist
+    idx = rng.randint(0, n_choices - 1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return idx
+    t = torch.tensor([idx], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    return int(t.item())

@@ -299,6 +299,12 @@ enum vam_family { VAM_FAM_CONV = 0, VAM_FAM_ATTN = 1, VAM_FAM_MASK = 2, VAM_FAM_
 int vam_prof_enable(int on);
 int vam_prof_reset(void);
 int vam_prof_read(int family, double* ms, long* launches, double* flops, double* bytes);
+/* Convolution launches are also summed per caller-defined class (which part of the model the launch belongs to:
+ * g_a, g_s, hyperprior, stack heads, slice chain ... — the host plan sets the class before each launch while the
+ * profiler is on), so that bench.py can report the roofline of the g_a/g_s conv stack on its own. */
+#define VAM_PROF_CLASSES 16
+int vam_prof_set_class(int cls);
+int vam_prof_read_class(int cls, double* ms, long* launches, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

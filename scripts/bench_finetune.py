@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--two-pass", action="store_true", help="separate ExtractChekpointRepr pass, as the reference loop")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: start the ranks as children (bench.py)
+        from bench import self_launch
+        sys.exit(self_launch(sys.argv[1:], a.gpus, script=__file__))
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     dist = None
     if world > 1:

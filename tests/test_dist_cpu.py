@@ -61,17 +61,31 @@ def test_shard_range_properties():
 def _grad_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2)),
+          torch.nn.Parameter(torch.zeros(4))]
     ps[0].grad = torch.full((3, 4), float(rank + 1))
     ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
-    nbytes = sharding.all_reduce_gradients(ps)                   # ps[2] has no gradient: skipped
-    q.put((rank, nbytes, ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad))
+    # ps[2]: no gradient on any rank.  ps[3]: only rank 1 produced one (e.g. its step touched another module)
+    if rank == 1:
+        ps[3].grad = torch.full((4,), 8.0)
+    nbytes = sharding.all_reduce_gradients(ps)
+    # a rank with NO gradients at all must still enter the collective (the old early return hung the others)
+    qs = [torch.nn.Parameter(torch.zeros(6))]
+    if rank == 0:
+        qs[0].grad = torch.full((6,), 2.0)
+    sharding.all_reduce_gradients(qs)
+    import random
+    rng = random.Random(1234 + 77 * rank)                      # ranks would draw different values on their own
+    picks = [sharding.broadcast_choice(1000, rng) for _ in range(5)]
+    q.put((rank, nbytes, ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad, ps[3].grad.clone(), qs[0].grad.clone(), picks))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gradient_all_reduce_two_ranks():
-    """The fine-tune step's only collective: one flat bucket, mean over ranks (REM gradients)."""
+    """The fine-tune step's only collective: one flat bucket with a rank-invariant layout, mean over ranks; ranks that
+    would otherwise hold gradients of different parameter subsets neither mix them nor hang; per-step random
+    choices come from rank 0."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -82,11 +96,17 @@ def test_gradient_all_reduce_two_ranks():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    for rank, nbytes, g0, g1, g2 in res:
-        assert nbytes == 17 * 4
+    for rank, nbytes, g0, g1, g2, g3, h0, picks in res:
+        assert nbytes == (12 + 5 + 2 + 4 + 4) * 4             # every parameter + one presence word each
         assert torch.equal(g0, torch.full((3, 4), 1.5))
         assert torch.equal(g1, torch.arange(5, dtype=torch.float32) * 1.5)
-        assert g2 is None
+        assert g2 is None                                       # untouched everywhere: the optimiser skips it
+        assert torch.equal(g3, torch.full((4,), 4.0))           # (0 + 8) / 2 on BOTH ranks, on the right parameter
+        assert torch.equal(h0, torch.full((6,), 1.0))
+    assert res[0][7] == res[1][7]                               # the sampled indices agree (rank 0 draws)
+    import random
+    r0 = random.Random(1234)
+    assert res[0][7] == [r0.randint(0, 999) for _ in range(5)]
 
 
 def test_finetune_host_logic():
@@ -106,3 +126,25 @@ def test_finetune_host_logic():
     n_pix = 2 * 8 * 8
     assert abs(float(c["bpp_base"]) - 32 * 1.0 / n_pix) < 1e-6 and abs(float(c["bpp_hype"]) - 4 * 2.0 / n_pix) < 1e-6
     assert abs(float(c["loss"]) - (32 + 2 * 8) / n_pix) < 1e-6 and float(c["mse_loss"].mean()) == 0.0
+
+
+def test_bench_entry_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it): the parent starts two ranks
+    through torch.distributed.run before touching any GPU and relays rank 0's JSON line.  --dry skips the GPU step;
+    rank set-up, the barrier-bracketed timing, max-over-ranks and the whole-job rate are the real code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VAMPIC_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                              # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 64
+    assert rec["ms_per_step"] >= 2.0                              # rank 1 sleeps 2 ms per step: the slowest rank sets the time
+    assert abs(rec["value"] - 2 * 32 * 65536 * 4 / 1e6 / (rec["ms_per_step"] * 4e-3)) / rec["value"] < 1e-3

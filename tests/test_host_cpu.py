@@ -131,6 +131,17 @@ def test_checkpoint_helpers_match_reference():
         lin2 = torch.nn.Linear(3, 2)
         assert ck.load_checkpoint(best, lin2)["epoch"] == 4 and ck.load_checkpoint(last)["epoch"] == 3
         assert all(torch.equal(a_, b_) for a_, b_ in zip(lin.state_dict().values(), lin2.state_dict().values()))
+        # the reference stores its argparse.Namespace beside the tensors (train.py:371-383): the safe loader takes it;
+        # anything else needs the explicit opt-in
+        ck.save_checkpoint({"epoch": 5, "state_dict": lin.state_dict(), "args": argparse.Namespace(N=192, M=640)}, False, last, best)
+        assert ck.load_checkpoint(last)["args"].M == 640
+        ck.save_checkpoint({"epoch": 6, "state_dict": lin.state_dict(), "opt": torch.optim.SGD}, False, last, best)
+        try:
+            ck.load_checkpoint(last)
+            raise AssertionError("an arbitrary pickled class must not load without allow_pickle")
+        except RuntimeError as e:
+            assert "allow_pickle" in str(e)
+        assert ck.load_checkpoint(last, allow_pickle=True)["epoch"] == 6
     args = argparse.Namespace(learning_rate=1e-4, aux_learning_rate=1e-3, training_type="rems")
     net = torch.nn.Module()
     net.a = torch.nn.Linear(2, 2)
