@@ -685,6 +685,7 @@ class _FsqPlan:
         # ---- hyperprior                                                            pic.py:278-298
         z = plan.buf(B, h // 4, w // 4, m.N)
         plan.set_class("hyperprior")
+        self.z = z
         E.lower_stacks(plan, [m.h_a], [[y]], [z])
         self.z_hat = plan.buf(B, h // 4, w // 4, m.N)
         self.z_lik = plan.buf(B, h // 4, w // 4, m.N)
@@ -697,6 +698,7 @@ class _FsqPlan:
         nh = 1 if base_only else 2
         means_h = plan.buf(B, h, w, nh * d)
         scales_h = plan.buf(B, h, w, nh * d)
+        self.means_h, self.scales_h = means_h, scales_h
         E.lower_stacks(plan, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)],
                        [[self.z_hat]] * (2 * nh),
                        [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
@@ -834,6 +836,7 @@ class _FsqPlan:
                 bw = self.bwd = E.Plan(device)
                 self.glik = bw.buf(B, h, w, d)
                 dmu, dsg = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                self.dmu, self.dsg, self.rem_io = dmu, dsg, rem_io     # kept for teacher-forced gradient checks
                 flat = torch.zeros(sum(p.numel() for p in self.rem_params), **f32)
                 self.gflat, self.gviews, off = flat, [], 0
                 for p in self.rem_params:

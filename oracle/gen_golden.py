@@ -220,6 +220,39 @@ def main():
     with open(os.path.join(GOLD, "host_utils.json"), "w") as f:
         json.dump(util, f)
 
+    # 8. BASELINE configs[0]: the demo's workload — ONE 256x256 image at the 15 quality levels of the demo's parser
+    #    (test/parser.py:20).  Stored: mask bit-packs, per-slice thresholds, PSNR / bpp scalars, strided samples.
+    DEMO_Q = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1, 2, 3, 4, 4.5, 10]      # base + parser.py:20
+    #    Run on the reference's plain "pic" model (demo.py --model pic) with the same weights: its output dict carries
+    #    the sigma the mask was computed from ("std", pic.py:661-666); the REM class returns std_base + sigma under
+    #    "std_prog" instead (rem_pic.py:343,417-422).
+    pargs = argparse.Namespace(**{**vars(args), "model": "pic"})
+    pic = quiet(get_model, pargs, "cpu").eval()
+    own = pic.state_dict()
+    torch.nn.Module.load_state_dict(pic, {k: v for k, v in sd.items() if k in own})
+    assert all(k in sd for k in own)
+    rec, scal = {}, {}
+    x = synth.synth_image(1, 256, 256, seed=0)
+    with torch.no_grad():
+        for q in DEMO_Q:
+            o = pic.forward_single_quality(x, quality=q, training=False)
+            o_std = o["std"]
+            tag = f"q{q}"
+            rec[tag + "_y_hat"] = o["y_hat"][:, ::4, ::2, ::2].numpy()
+            rec[tag + "_x_hat"] = o["x_hat"][:, :, ::8, ::8].numpy()
+            if q > 0:      # the reference does not return its masks: re-apply ITS ChannelMask to the sigma it returns (pic.py:621-622)
+                m = torch.cat([pic.masking(s_, pr=q, mask_pol="point-based-std") for s_ in o_std.chunk(10, 1)], 1)
+                rec[tag + "_mask"] = np.packbits(m.numpy().astype(np.uint8).reshape(-1))
+            if 0 < q < 10:
+                rec[tag + "_thr"] = np.array([torch.quantile(s_.ravel(), 1.0 - q * 0.1).item()
+                                              for s_ in o_std[0].chunk(10, 0)], dtype=np.float32)
+            mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
+            bits = sum(torch.log(v.double()).sum().item() for v in o["likelihoods"].values()) / (-np.log(2) * 65536)
+            scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
+    np.savez_compressed(os.path.join(GOLD, "demo_256.npz"), **rec)
+    with open(os.path.join(GOLD, "demo_256.json"), "w") as f:
+        json.dump(scal, f, indent=1)
+
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):
         print(f"  {fn}: {os.path.getsize(os.path.join(GOLD, fn)) / 1024:.1f} KiB")

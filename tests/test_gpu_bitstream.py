@@ -120,6 +120,39 @@ def test_progressive_container_layers(codec):
             assert (dk["x_hat"].clamp(0, 1) - fw["x_hat"]).abs().max().item() <= 1e-5
 
 
+def test_demo_flow_single_256_image(codec):
+    """BASELINE configs[0] (reference demo.py on one 256x256 image, --model pic, the parser's 15 q_levs,
+    test/parser.py:20): progressive encode -> decode of every layer, plus compress / decompress per level.  Decoding k
+    layers must give what forward_single_quality(q_k) reconstructs; the real-codec path must equal the likelihood path
+    bit for bit (the decoder reproduces the encoder's masks and indexes or the range coder desynchronises)."""
+    from vampic import progressive as P
+    net = codec
+    x = synth.synth_image(1, 256, 256, seed=0).cuda()
+    q_list = [0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1, 2, 3, 4, 4.5, 10]
+    bit, (bz, bb, bl) = P.encode(net, x, q_list=q_list)
+    assert len(bit["progressive"]) == len(q_list) and bz > 0 and bb > 0
+    with torch.no_grad():
+        d0 = P.decode(net, bit, q_ind=0)
+        fw0 = net.forward_single_quality(x, 0)
+        assert (d0["x_hat"] - fw0["x_hat"]).abs().max().item() <= 1e-5
+        state = {}
+        prev_bits = 0
+        for k in range(1, len(q_list) + 1):
+            dk = P.decode(net, bit, q_ind=k, z_data=state.get("z"), res_base=d0["res_base"], entropy_data=state.get("e"))
+            state = {"z": dk["z_data"], "e": dk["entropy_data"]}
+            fw = net.forward_single_quality(x, q_list[k - 1])
+            assert (dk["y_prog"] - fw["y_hat"]).abs().max().item() <= 1e-4, k
+            assert (dk["x_hat"].clamp(0, 1) - fw["x_hat"]).abs().max().item() <= 1e-5, k
+            bits = sum(bl[:k])
+            assert bits > prev_bits                          # every layer adds latents (masks are nested in q)
+            prev_bits = bits
+        for q in (0, 0.25, 1, 4.5, 10):
+            fw = net.forward_single_quality(x, q)
+            enc = net.compress(x, quality=q)
+            dec = net.decompress(enc["strings"], enc["shape"], quality=q)
+            assert torch.equal(dec["x_hat"], fw["x_hat"]), q
+
+
 def test_eval_drivers(codec):
     """test_epoch / compress_with_ac counterparts (reference training/step.py:206-358) incl. padding of a
     non-multiple-of-64 image and PSNR via vam_sqdiff_sum."""

@@ -56,6 +56,38 @@ def test_full_size_stagewise(gpu_model, shape, q):
     ref_x = O.g_s(sd, "g_s.1.", cpu["y_hat"][sel]).clamp(0, 1)
     assert (cpu["x_hat"][sel] - ref_x).abs().max().item() <= 1e-4
     assert cpu["x_hat"].min() >= 0 and cpu["x_hat"].max() <= 1
+    # (4b) EVERY conv family at full size, teacher-forced on the GPU's own inputs (images 0 and last):
+    #      g_a (both encoders), h_a, the four hyper-synthesis stacks, a base mean / scale / LRP stack, a progressive
+    #      mean / scale / LRP stack
+    def close(got, ref, tol, what):
+        err = (got - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (what, err, ref.abs().max().item())
+    xs = x.cpu()[sel]
+    ys = y[sel]
+    close(ys[:, :320], O.g_a(sd, "g_a.0.", xs), 1e-4, "g_a.0")
+    close(ys[:, 320:], O.g_a(sd, "g_a.1.", xs), 1e-4, "g_a.1")
+    close(plan.z.torch_nchw().cpu()[sel], O.h_a(sd, ys), 1e-4, "h_a")
+    mh, sh = plan.means_h.torch_nchw().cpu()[sel], plan.scales_h.torch_nchw().cpu()[sel]
+    for k in (0, 1):
+        close(mh[:, 320 * k:320 * (k + 1)], O.h_s(sd, f"h_mean_s.{k}.", z_hat), 1e-4, f"h_mean_s.{k}")
+        close(sh[:, 320 * k:320 * (k + 1)], O.h_s(sd, f"h_scale_s.{k}.", z_hat), 1e-4, f"h_scale_s.{k}")
+    yb, mub, sdb = cpu["y_base"][sel], cpu["mu_base"][sel], cpu["std_base"][sel]
+    close(mub[:, 96:128], O.cc_stack(sd, "cc_mean_transforms.3.", torch.cat([mh[:, :320], yb[:, :96]], 1)), 3e-4, "cc_mean.3")
+    close(sdb[:, 224:256], O.cc_stack(sd, "cc_scale_transforms.7.", torch.cat([sh[:, :320], yb[:, :160]], 1)), 3e-4, "cc_scale.7")
+    yq2 = torch.round(ys[:, 64:96] - mub[:, 64:96]) + mub[:, 64:96]
+    lrp = O.cc_stack(sd, "lrp_transforms.2.", torch.cat([mh[:, :320], yb[:, :64], yq2], 1))
+    close(yb[:, 64:96], yq2 + 0.5 * torch.tanh(lrp), 3e-4, "lrp.2")
+    std_p = plan.std_p.torch_nchw().cpu()[sel]                # progressive sigma chain (before any REM)
+    mu_p = plan.mu_p.torch_nchw().cpu()[sel]
+    ssup = torch.cat([sh[:, 320:], yb[:, 192:224], std_p[:, 32:192]], 1)
+    close(std_p[:, 192:224], O.cc_stack(sd, "cc_scale_transforms_prog.6.", ssup), 3e-4, "cc_scale_prog.6")
+    mu_tot = mu_p + yb
+    msup9 = torch.cat([mh[:, 320:], yb[:, 288:320], mu_tot[:, 128:288]], 1)
+    close(mu_p[:, 288:320], O.cc_stack(sd, "cc_mean_transforms_prog.9.", msup9), 3e-4, "cc_mean_prog.9")
+    r9 = ys[:, 608:640] - ys[:, 288:320]
+    rq9 = torch.round(r9 - mu[sel][:, 288:320]) * mask[sel][:, 288:320] + mu[sel][:, 288:320]
+    lrp = O.cc_stack(sd, "lrp_transforms_prog.9.", torch.cat([msup9, rq9], 1))
+    close(cpu["y_hat"][sel][:, 288:320], rq9 + 0.5 * torch.tanh(lrp) + yb[:, 288:320], 3e-4, "lrp_prog.9")
     # (5) determinism: graph replay reproduces every bit
     with torch.no_grad():
         again = net.forward_single_quality(x, q)

@@ -42,26 +42,40 @@ def test_thresholds_bit_exact():
         assert np.array_equal(thr.cpu().numpy(), gold[f"s8192_q{q}_thr"]), q
 
 
-def _check_against_vectors(tag, x, o, gold, scal, n_pix):
-    """Strict when no latent sits on a rounding boundary (the normal case); otherwise the
-    flip-aware bound of tests/test_gpu_model.py (fp32 summation order)."""
+def _check_against_vectors(tag, x, o, gold, scal, n_pix, net=None, sd=None, q=None, shape=None):
+    """Strict when no rounding decision differs (the normal case).  Otherwise the differences must be PROVEN boundary
+    events (tests/parity_audit.py, against the oracle, which the CPU suite pins to these same vectors) and stay inside
+    the flip-aware bounds (fp32 summation order)."""
     ref_y = torch.from_numpy(gold[tag + "_y_hat"])
     flips = int((torch.round(o["y_hat"].cpu() - ref_y).abs() >= 1).sum())
     x_err = (o["x_hat"].cpu() - torch.from_numpy(gold[tag + "_x_hat"])).abs().max().item()
+    aud = None
+    if net is not None:
+        import vampic_oracle as O
+        from parity_audit import audit, gpu_latent
+        ref = O.forward_single_quality(sd, x, q)
+        aud = audit(gpu_latent(net, *shape, q == 0), {k: v.cpu() for k, v in o.items() if torch.is_tensor(v)}, ref, q)
+        assert aud["violations"] == [], (tag, aud)
+        if flips == 0 and (aud["sym_flips"] or aud["mask_flips"]):
+            flips = aud["sym_flips"] + aud["mask_flips"]          # a flip the LRP happened to hide in y_hat
     if flips == 0:
         assert x_err <= 1e-4, tag
+        if tag + "_mask" in gold.files:                              # reference-generated mask bits: identical
+            m = o["mask"].cpu().numpy().astype(np.uint8)
+            assert np.array_equal(np.packbits(m.reshape(-1)), gold[tag + "_mask"]), tag
         if scal is not None:
             mse = torch.nn.functional.mse_loss(x, o["x_hat"].cpu()).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
             bpp = -o["log2_likelihood_sum"].sum().item() / n_pix
             assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
         return True
+    print("boundary hit", tag, flips, None if aud is None else {k: aud[k] for k in ("first", "explained", "downstream")})
     assert flips <= 0.02 * ref_y.numel() and x_err <= 0.5, (tag, flips, x_err)
     return False
 
 
 def test_forward_matches_reference_vectors(gpu_model):
-    net, _ = gpu_model
+    net, sd = gpu_model
     gold = np.load(os.path.join(GOLD, "forward_single_quality.npz"))
     scal = json.load(open(os.path.join(GOLD, "forward_single_quality.json")))
     clean = total = 0
@@ -70,11 +84,65 @@ def test_forward_matches_reference_vectors(gpu_model):
         for q in (0, 0.5, 2.5, 10):
             with torch.no_grad():
                 o = net.forward_single_quality(x.cuda(), q)
-            clean += _check_against_vectors(f"s{seed}_q{q}", x, o, gold, scal, 4096)
+            clean += _check_against_vectors(f"s{seed}_q{q}", x, o, gold, scal, 4096, net, sd, q, (1, 64, 64))
             total += 1
     x = synth.synth_image(1, 64, 128, seed=0)
     with torch.no_grad():
         o = net.forward_single_quality(x.cuda(), 2.5, checkpoint_ref=torch.from_numpy(gold["rem_ck"]).cuda())
     clean += _check_against_vectors("rem", x, o, gold, None, 8192)
     total += 1
-    assert clean * 2 >= total, f"only {clean}/{total} reference vectors reproduced in every rounding decision"
+    print(f"reference vectors reproduced in every rounding decision: {clean}/{total}")
+    assert clean >= 0.85 * total, f"only {clean}/{total} reference vectors reproduced in every rounding decision"
+
+
+# ---- BASELINE configs[0]: the demo's workload, one 256x256 image (reference demo.py / test/parser.py:20 q_levs)
+DEMO_Q = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1, 2, 3, 4, 4.5, 10]
+
+
+def test_demo_image_256_matches_reference_vectors(gpu_model):
+    """BASELINE configs[0] workload: forward_single_quality of ONE 256x256 image at the demo's 15 quality levels
+    against vectors the REFERENCE produced (oracle/gen_golden.py section 8): mask bit-packs and thresholds (rate-point
+    selection) bit for bit, PSNR / bpp scalars, strided samples of x_hat / y_hat.  A level with a differing rounding
+    decision must pass the boundary audit instead."""
+    import vampic_oracle as O
+    from parity_audit import audit, gpu_latent
+    net, sd = gpu_model
+    gold = np.load(os.path.join(GOLD, "demo_256.npz"))
+    scal = json.load(open(os.path.join(GOLD, "demo_256.json")))
+    x = synth.synth_image(1, 256, 256, seed=0)
+    clean = total = 0
+    for q in DEMO_Q:
+        tag = f"q{q}"
+        with torch.no_grad():
+            o = net.forward_single_quality(x.cuda(), q)
+        ref = O.forward_single_quality(sd, x, q)
+        cpu = {k: v.cpu() for k, v in o.items() if torch.is_tensor(v)}
+        aud = audit(gpu_latent(net, 1, 256, 256, q == 0), cpu, ref, q)
+        assert aud["violations"] == [], (tag, aud)
+        total += 1
+        ys, xs = cpu["y_hat"][:, ::4, ::2, ::2].numpy(), cpu["x_hat"][:, :, ::8, ::8].numpy()
+        if aud["sym_flips"] or aud["mask_flips"]:
+            print("boundary hit", tag, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
+            assert aud["sym_flips"] <= 0.02 * cpu["y_hat"].numel() and np.abs(xs - gold[tag + "_x_hat"]).max() <= 0.5
+            continue
+        clean += 1
+        if q > 0:
+            m = cpu["mask"].numpy().astype(np.uint8)
+            assert np.array_equal(np.packbits(m.reshape(-1)), gold[tag + "_mask"]), tag     # reference's mask bits
+        if 0 < q < 10:
+            assert np.array_equal(gold[tag + "_thr"], _thresholds(net, 1, 256, 256)), tag   # reference's thresholds
+        assert np.abs(ys - gold[tag + "_y_hat"]).max() <= 2e-4 * max(1.0, np.abs(gold[tag + "_y_hat"]).max()), tag
+        assert np.abs(xs - gold[tag + "_x_hat"]).max() <= 1e-4, tag
+        mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
+        assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
+        bpp = -cpu["log2_likelihood_sum"].sum().item() / 65536
+        assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
+    print(f"256x256 demo image: {clean}/{total} quality levels reproduced in every rounding decision")
+    assert clean >= 0.8 * total
+
+
+def _thresholds(net, B, H, W):
+    for k, p in net._plans.items():
+        if k[:5] == (B, H, W, False, None) and len(k) == 6:
+            return p.thr.cpu().numpy()
+    raise KeyError

@@ -29,53 +29,71 @@ def _cmp(out, ref, B, H, W, q):
     return rep
 
 
-# fp32 accumulation order differs between any two conv back-ends (here: MFMA k-order vs MKLDNN),
-# which perturbs y - mu by ~1e-5..1e-4; an element within that distance of a rounding boundary
-# flips its symbol, and every later slice is conditioned on it (chaotic cascade).  The strict
-# north-star tolerances therefore hold exactly when no element sits on a boundary.  The test scans
-# seeds: every (seed, q) case WITHOUT a boundary hit must meet the strict tolerances (every mask
-# bit and symbol identical, |dPSNR| <= 1e-4 dB, |dbpp| <= 1e-6 rel), cases WITH a hit must stay
-# within the flip-aware bounds, and at least half of the cases must be boundary-free (a real
-# bug would flip far more than the fp32-noise rate).
+# fp32 accumulation order differs between any two conv back-ends (here: MFMA k-order vs MKLDNN), which perturbs
+# y - mu by ~1e-5 of its magnitude; an element within that distance of a rounding boundary flips its symbol, and every
+# later slice is conditioned on it.  The strict north-star tolerances therefore hold exactly when no element sits on a
+# boundary.  The gate (tests/parity_audit.py):
+#   * a case WITHOUT any differing rounding decision must meet the strict tolerances (every mask bit and symbol
+#     identical, |dPSNR| <= 1e-4 dB, |dbpp| <= 1e-6 * max(1, bpp));
+#   * in a case WITH differences, every difference in a slice whose inputs still agree must be a PROVEN boundary event
+#     in the oracle's own numbers (residual within 1e-3 of x.5 / sigma within 2e-4 of the threshold); only slices
+#     downstream of such an event may differ freely, and then by bounded counts;
+#   * at least 90 % of the cases must be difference-free (a real bug flips far more than the fp32-noise rate).
 SHAPES = [(1, 64, 64), (1, 64, 128), (1, 128, 128)]
 QS = [0, 0.5, 2.5, 10]
+MIN_CLEAN_FRACTION = 0.9
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-def test_forward_single_quality_parity(gpu_model, shape):
-    net, sd = gpu_model
+def _one_case(net, sd, shape, seed, q):
+    from parity_audit import audit, gpu_latent
     B, H, W = shape
+    x = vampic.synth.synth_image(B, H, W, seed=seed)
+    ref = O.forward_single_quality(sd, x, q)
+    with torch.no_grad():
+        out = net.forward_single_quality(x.cuda(), q, training=False)
+    rep = _cmp(out, ref, B, H, W, q)
+    cpu = {k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}
+    aud = audit(gpu_latent(net, B, H, W, q == 0), cpu, ref, q)
+    psnr_g, psnr_r = O.psnr(x, out["x_hat"].cpu()), O.psnr(x, ref["x_hat"])
+    n = out["y_hat"].numel()
+    assert aud["violations"] == [], (shape, seed, q, aud)        # every first difference is a proven boundary event
+    if aud["sym_flips"] == 0 and aud["mask_flips"] == 0:
+        assert rep["latent_symbol_flips"] == 0 and rep.get("mask_flips", 0) == 0, (shape, seed, q, rep)
+        assert abs(psnr_g - psnr_r) <= 1e-4, (shape, seed, q, psnr_g, psnr_r)          # dB
+        tol = 1e-6 * max(1.0, rep["bpp_ref"])
+        assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
+        assert abs(rep["bpp_kernel"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
+        for k in ("y_hat", "mu_base", "std_base"):
+            a, b = out[k].cpu(), ref[k]
+            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (shape, seed, q, k)
+        return True
+    print("boundary hit", shape, seed, q, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
+    assert aud["sym_flips"] <= 0.05 * n and aud["mask_flips"] <= 0.03 * n, aud           # cascade after an early flip
+    assert abs(psnr_g - psnr_r) <= 0.1 and abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= 5e-3 * rep["bpp_ref"], rep
+    return False
+
+
+def test_forward_single_quality_parity(gpu_model):
+    net, sd = gpu_model
     clean = total = 0
-    for seed in range(4):
-        x = vampic.synth.synth_image(B, H, W, seed=seed)
-        for q in QS:
-            ref = O.forward_single_quality(sd, x, q)
-            with torch.no_grad():
-                out = net.forward_single_quality(x.cuda(), q, training=False)
-            rep = _cmp(out, ref, B, H, W, q)
-            psnr_g, psnr_r = O.psnr(x, out["x_hat"].cpu()), O.psnr(x, ref["x_hat"])
-            n = out["y_hat"].numel()
-            total += 1
-            if rep["latent_symbol_flips"] == 0 and rep.get("mask_flips", 0) == 0:
-                clean += 1
-                assert abs(psnr_g - psnr_r) <= 1e-4, (shape, seed, q, psnr_g, psnr_r)          # dB
-                tol = 1e-6 * max(1.0, rep["bpp_ref"])
-                assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
-                assert abs(rep["bpp_kernel"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
-                for k in ("y_hat", "mu_base", "std_base"):
-                    a, b = out[k].cpu(), ref[k]
-                    assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (shape, seed, q, k)
-            else:
-                print("boundary hit", shape, seed, q, rep)
-                assert rep["latent_symbol_flips"] <= 0.05 * n and rep.get("mask_flips", 0) <= 0.03 * n, rep   # cascade after an early flip
-                assert abs(psnr_g - psnr_r) <= 0.1 and abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= 5e-3 * rep["bpp_ref"], rep
-    print(shape, f"boundary-free cases: {clean}/{total}")
-    assert clean * 2 >= total, f"only {clean}/{total} cases agree in every rounding decision"
+    per_shape = {}
+    for shape in SHAPES:
+        c = 0
+        for seed in range(4):
+            for q in QS:
+                ok = _one_case(net, sd, shape, seed, q)
+                c += ok
+                clean += ok
+                total += 1
+        per_shape[shape] = c
+    print(f"difference-free cases: {clean}/{total}  per shape {per_shape}")
+    assert clean >= MIN_CLEAN_FRACTION * total, f"only {clean}/{total} cases agree in every rounding decision: {per_shape}"
 
 
 def test_forward_batch_nonsquare_flip_aware(gpu_model):
-    """Batch 2, non-square 128x192: boundary hits are possible; every disagreement must be a
-    consequence of symbol flips (bounded in number), never a gross error."""
+    """Batch 2, non-square 128x192: boundary hits are possible; every disagreement must be a proven boundary event or
+    downstream of one (bounded in number), never a gross error."""
+    from parity_audit import audit, gpu_latent
     net, sd = gpu_model
     B, H, W = 2, 128, 192
     x = vampic.synth.synth_image(B, H, W, seed=1)
@@ -83,9 +101,11 @@ def test_forward_batch_nonsquare_flip_aware(gpu_model):
     with torch.no_grad():
         out = net.forward_single_quality(x.cuda(), 2.5)
     rep = _cmp(out, ref, B, H, W, 2.5)
-    print("flip-aware", rep)
+    aud = audit(gpu_latent(net, B, H, W, False), {k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}, ref, 2.5)
+    print("flip-aware", rep, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
+    assert aud["violations"] == [], aud
     n = out["y_hat"].numel()
-    assert rep["latent_symbol_flips"] <= 0.05 * n and rep["mask_flips"] <= 0.03 * n, rep
+    assert aud["sym_flips"] <= 0.05 * n and aud["mask_flips"] <= 0.03 * n, aud
     # slices before the first flip agree to float tolerance: the analysis transform and slice 0
     assert (out["mu_base"][:, :32].cpu() - ref["mu_base"][:, :32]).abs().max() <= 2e-4 * ref["mu_base"].abs().max()
     assert abs(O.psnr(x, out["x_hat"].cpu()) - O.psnr(x, ref["x_hat"])) <= 0.1

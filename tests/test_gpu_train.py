@@ -267,6 +267,57 @@ def test_fused_finetune_forward_equals_two_pass(train_model):
         assert torch.equal(a, b)
 
 
+def test_rem_finetune_step_full_size_teacher_forced(train_model):
+    """BASELINE configs[4] at its stated per-GPU size: one fused fine-tune step (check level 0.75 -> q = 2.5) on
+    16 x 3 x 256 x 256.  The step's REM gradients are checked teacher-forced: autograd over the ORACLE's rem_block, fed
+    the HIP plan's own REM inputs (checkpoint latent, base / progressive entropy parameters, attention mask) and its own
+    dL/d(mu', sigma'), must reproduce the gradient of every parameter of the checked slices (2e-5 of its max) — the sum
+    over all 16 images and 256 latent positions, i.e. the full-size reduction the wgrad kernel performs."""
+    m0, sd = train_model
+    m = copy.deepcopy(m0)
+    m.use_graph = True
+    B, H, W, q = 16, 256, 256, 2.5
+    x = synth.synth_image(B, H, W, seed=21).cuda()
+    noise = {"y": (synth.uniform((B, 640, 16, 16), 31) - 0.5).cuda(), "z": (synth.uniform((B, 192, 4, 4), 32) - 0.5).cuda()}
+    m.zero_grad(set_to_none=True)
+    out = m.forward_finetune(x, q, noise=noise)
+    loss = _rate_loss(out, x)
+    loss.backward()
+    assert torch.isfinite(loss) and float(loss) > 0
+    plan = [p for k, p in m._plans.items() if "train" in k and k[:3] == (B, H, W)][0]
+    ck, epb, epp, att, _ = plan.rem_io
+    N = 32
+    nchw = lambda v: v.torch_nchw().detach().cpu().clone()
+    for j in (0, 4, 9):
+        leaves = {"r." + n: t.detach().cpu().clone().requires_grad_(True) for n, t in m.post_latent[0][j].state_dict().items()}
+        a = nchw(att[j])
+        res = O.rem_block(leaves, "r.", nchw(ck[j]), torch.cat([nchw(epb[j][0]), nchw(epb[j][1])], 1),
+                          torch.cat([nchw(epp[j][0]), nchw(epp[j][1])], 1), torch.cat([a, a], 1))
+        dres = torch.cat([nchw(plan.dmu.window(j * N, N)), nchw(plan.dsg.window(j * N, N))], 1)
+        res.backward(dres)
+        # forward agreement of the refined parameters on the same inputs
+        got = torch.cat([nchw(plan.mu_f.window(j * N, N)), nchw(plan.std_f.window(j * N, N))], 1)
+        assert _rel(got, res) <= 1e-5, j
+        for n, p in m.post_latent[0][j].named_parameters():
+            assert p.grad is not None, (j, n)
+            assert _rel(p.grad, leaves["r." + n].grad) <= 2e-5, (j, n, _rel(p.grad, leaves["r." + n].grad))
+    # the other REMs (other check levels) and everything frozen stay without gradients
+    assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("post_latent.0."))
+    # likelihood backward at full size against the oracle's autograd on the plan's own (y, mu', sigma', mask, noise)
+    d = 320
+    y = plan.y.torch_nchw().detach().cpu()
+    mu = nchw(plan.mu_f).requires_grad_(True)
+    sg = nchw(plan.std_f).requires_grad_(True)
+    mk = nchw(plan.mask)
+    lik = O.gaussian_likelihood_noise(((y[:, d:] - y[:, :d]) - mu) * mk, sg * mk, None, noise["y"][:, d:].cpu())
+    assert float((lik.detach() - out["likelihoods"]["y"][:, d:].detach().cpu()).abs().max()) <= 1e-6
+    den = -math.log(2) * B * H * W
+    (torch.log(lik).sum() / den).backward()
+    for got, ref in ((plan.dmu, mu.grad), (plan.dsg, sg.grad)):
+        dd = (nchw(got) - ref).abs()
+        assert float(dd.max()) <= 2e-5 * float(ref.abs().max()) + 1e-9, float(dd.max())
+
+
 def test_training_outside_rem_fails_loudly(train_model):
     m0, _ = train_model
     m = copy.deepcopy(m0)

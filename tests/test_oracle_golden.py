@@ -136,3 +136,63 @@ def test_rem_training_step_matches_reference(synth_model_cpu):
         assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
         assert np.abs(s - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-10, name
     assert off == len(samples)
+
+
+def test_flip_audit_separates_boundary_events_from_errors(synth_model_cpu):
+    """tests/parity_audit.py (the gate of the GPU end-to-end parity tests) on CPU: two oracle runs whose inputs differ
+    by 2e-7 play "reference" and "other back-end" — every differing rounding decision must be classified as a
+    boundary event; a shifted mean (a genuine error) must be reported as a violation."""
+    import copy
+    import vampic
+    from parity_audit import audit
+    _, sd = synth_model_cpu
+    x = vampic.synth.synth_image(1, 64, 128, seed=3)
+    ref = O.forward_single_quality(sd, x, 2.5)
+    oth = O.forward_single_quality(sd, (x + 2e-7 * (vampic.synth.uniform(tuple(x.shape), 9) - 0.5)).float(), 2.5)
+    rep = audit(oth["y"], oth, ref, 2.5)
+    assert rep["violations"] == [], rep
+    assert rep["sym_flips"] + rep["mask_flips"] == rep["explained"] + rep["downstream"]
+    same = audit(ref["y"], ref, ref, 2.5)
+    assert same["sym_flips"] == 0 and same["mask_flips"] == 0 and same["first"] is None and same["violations"] == []
+    bad = copy.deepcopy(ref)
+    bad["mu_base"] = ref["mu_base"].clone()
+    bad["mu_base"][:, 32:64] += 0.3                      # wrong mean in base slice 1: symbols move, not at boundaries
+    rep = audit(ref["y"], bad, ref, 2.5)
+    assert rep["violations"] and rep["first"] == "base 1", rep
+    near = copy.deepcopy(ref)                            # the kept element closest to the threshold drops out: a threshold event
+    near["mask"] = ref["mask"].clone()
+    s0 = ref["std"][0, :32]
+    thr = float(O.quantile_threshold_np(s0.numpy().ravel(), 0.25))
+    pos = torch.nonzero((s0 - thr).abs() == (s0 - thr).abs().min())[0]
+    if float((s0 - thr).abs().min()) < 2e-4:
+        near["mask"][0, pos[0], pos[1], pos[2]] = 1 - near["mask"][0, pos[0], pos[1], pos[2]]
+        rep = audit(ref["y"], near, ref, 2.5)
+        assert rep["violations"] == [] and rep["mask_flips"] == 1 and rep["explained"] >= 1, rep
+    bad = copy.deepcopy(ref)
+    bad["mask"] = ref["mask"].clone()
+    bad["mask"][:, :32] = 1 - ref["mask"][:, :32]        # a mask that is simply wrong
+    rep = audit(ref["y"], bad, ref, 2.5)
+    assert rep["violations"] and "threshold" in rep["violations"][0], rep
+
+
+def test_oracle_reproduces_reference_demo_image_256(synth_model_cpu):
+    """BASELINE configs[0] workload (one 256x256 image, the demo's q_levs, test/parser.py:20): the oracle against the
+    vectors the REFERENCE produced (oracle/gen_golden.py section 8) — mask bits and thresholds exactly."""
+    import vampic
+    _, sd = synth_model_cpu
+    gold = np.load(os.path.join(GOLD, "demo_256.npz"))
+    scal = json.load(open(os.path.join(GOLD, "demo_256.json")))
+    x = vampic.synth.synth_image(1, 256, 256, seed=0)
+    for q in (0, 0.01, 0.25, 0.6, 0.9, 2, 4.5, 10):                       # 8 of the 16 stored levels (CPU time)
+        tag = f"q{q}"
+        o = O.forward_single_quality(sd, x, q)
+        _close(o["y_hat"][:, ::4, ::2, ::2], gold[tag + "_y_hat"], 2e-5)
+        _close(o["x_hat"][:, :, ::8, ::8], gold[tag + "_x_hat"], 2e-5)
+        if q > 0:
+            assert np.array_equal(np.packbits(o["mask"].numpy().astype(np.uint8).reshape(-1)), gold[tag + "_mask"]), tag
+        if 0 < q < 10:
+            thr = np.array([O.quantile_threshold_np(s_.numpy().ravel(), q * 0.1) for s_ in o["std"][0].chunk(10, 0)],
+                           dtype=np.float32)
+            assert np.array_equal(thr, gold[tag + "_thr"]), tag
+        assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4
+        assert abs(O.bpp(o["likelihoods"], 65536) - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"])
