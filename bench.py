@@ -54,13 +54,27 @@ def build_model(device):
 
 
 def host_cores() -> int:
-    """Cores this process may run on (the one-GPU box hands out a CPU share, not the whole host)."""
+    """Cores this process may actually use: the smaller of its affinity mask and its cgroup CPU quota (the one-GPU box
+    hands out a CPU share of a larger host; asking ATen for more threads than the quota only thrashes)."""
     if os.environ.get("VAMPIC_CPU_THREADS"):
         return int(os.environ["VAMPIC_CPU_THREADS"])
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    try:                                                   # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def cpu_model() -> str:
@@ -81,12 +95,14 @@ def cpu_baseline(sd, H, W, quality, budget_s=24.0):
     import vampic_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} host threads ({cpu_model()})", file=sys.stderr, flush=True)
     x1 = vampic.synth.synth_image(1, H, W, seed=7)
     O.forward_single_quality(sd, x1, quality)                      # first call: page-in, thread pool start
     t0 = time.perf_counter()
     O.forward_single_quality(sd, x1, quality)                      # calibration
     t1 = time.perf_counter() - t0
     nb = max(1, min(8, int(budget_s / 7 / max(t1, 1e-3))))
+    print(f"[bench] cpu_baseline: {t1:.2f} s per image -> sample of {nb} images x 7 runs", file=sys.stderr, flush=True)
     x = vampic.synth.synth_image(nb, H, W, seed=8)
     for _ in range(2):
         O.forward_single_quality(sd, x, quality)

@@ -1,22 +1,30 @@
-// NHWC im2col-free convolution as an implicit GEMM on the CDNA4 fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD).
+// NHWC im2col-free convolution as an implicit GEMM on the CDNA4 matrix cores.
 //
 //   out[p, n] = post2 + post + mul * act( bias[n] + pre + sum_{ty,tx,c} in[pix(p)+(ty,tx), c] * W[ty,tx,c,n] )
 //
-// * M = output positions p=(b,oy,ox), N = output channels, K = taps x concatenated input
-//   channels.  The input is a virtual channel-concat of up to 4 NHWC "segments"
-//   (pointer + channel count + pixel stride), so torch.cat of the reference
-//   (models/pic.py:528-529,548,598-599,635) never materialises.
-// * Each K chunk (one tap, BK consecutive channels) of the A tile is BM rows of BK
-//   contiguous floats in HBM/L2 -> coalesced 16-byte loads, zero-filled at the halo,
-//   staged through LDS (row stride BK+4 floats: conflict-free ds_read_b128).
-// * Weights are pre-packed [tap][16-channel chunk][n][16] so a B tile is one or two contiguous blocks.
-// * Double-buffered LDS, next chunk prefetched into registers under the MFMAs,
-//   one barrier per chunk.
-// * Grouped launch: up to 8 independent problems share one grid; tiles are dealt to XCDs in
-//   contiguous runs (blocks b and b+8 share an XCD/L2) so neighbours reuse A rows and halos.
-// * Tile shapes cover the model's channel counts without padding waste: BN in
-//   {32,64,96,128,160,192,224}, BM in {64,128}.
+// Two arithmetic modes, one kernel template (MODE):
+//   MODE 1 (default): every fp32 operand is split EXACTLY into three bf16 terms (hi + mid + lo) and the product is
+//           formed from six exact bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//           fp32 accuracy (error vs float64 no larger than the fp32 fma chain's) at 6/16 of the fp32 pipe's matrix time.
+//           Weights are split once at pack time ([tap][32-channel chunk][n][plane 3][group 4][8 bf16], 192 B per row,
+//           copied to LDS verbatim); fp32 activations are split while they are staged into LDS, or arrive already
+//           split as bf16x3 planes from the producing launch's epilogue (AIN = 1).  K step 32 channels; LDS rows of
+//           12 x 16 B, the group index XOR-swizzled with the row so that staging writes and operand reads are both
+//           bank-conflict free; tiles with BM + BN > 128 single-buffer LDS, smaller ones double-buffer.
+//   MODE 0 (VAMPIC_CONV=f32): fp32 operands on v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain, 64 FLOP/clk/SIMD),
+//           weights packed [tap][16-channel chunk][n][16] fp32, K step 16 or 32, double-buffered XOR-swizzled LDS.
+// Common to both:
+// * M = output positions p=(b,oy,ox), N = output channels, K = taps x concatenated input channels.  The input is a
+//   virtual channel-concat of up to 4 NHWC "segments" (pointer + channel count + pixel stride), so torch.cat of the
+//   reference (models/pic.py:528-529,548,598-599,635) never materialises.
+// * Each K chunk (one tap, BK consecutive channels) of the A tile is BM rows of BK contiguous channels in HBM/L2 ->
+//   coalesced 16-byte buffer loads, zero-filled at the halo by the hardware range check, staged through LDS; the next
+//   chunk is prefetched into registers under the MFMAs.
+// * Canonical K order (32-channel group outer, tap inner): a layer gives bit-identical results however it is tiled
+//   or grouped (the decoder must reproduce the encoder's sigma exactly).
+// * Grouped launch: up to 8 independent problems share one grid; every XCD gets a contiguous eighth of EACH problem's
+//   tiles (blocks b and b+8 share an XCD/L2) so neighbours reuse A rows and halos.
+// * The C tile is staged through LDS in 32-row slabs so the epilogue issues 16-byte loads / stores.
 //
 // Replaces nn.Conv2d / nn.ConvTranspose2d (per sub-pixel phase) / nn.Linear plus the
 // surrounding element-wise ops of reference layers/layers.py:5-86, layers/gdn.py:62-75,
@@ -427,12 +435,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
         const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
         const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
 #pragma unroll
+#if defined(VAM_DIAG) && (VAM_DIAG & 16)
+        for (int q = 0; q < NAR; ++q) { ra[i][q].x = off + q; ra[i][q].y = 0x3f803f80u; ra[i][q].z = 0x3c003c00u; ra[i][q].w = 0x38003800u; }
+#else
         for (int q = 0; q < NAR; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * q), 0, 0);
+#endif
       }
       // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
       const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 192u;
 #pragma unroll
+#if defined(VAM_DIAG) && (VAM_DIAG & 8)
+      for (int j = 0; j < NBC; ++j) { rb[j].x = wbase + j; rb[j].y = 0x3f803f80u; rb[j].z = 0x3c003c00u; rb[j].w = 0x38003800u; }
+#else
       for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
+#endif
       // canonical K order: 32-channel group OUTER, tap INNER
       ++c_tap;
       ++c_tx;
@@ -452,6 +468,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         if (A_FULL || ld_row + i * RPP < BM) {
+#if defined(VAM_DIAG) && (VAM_DIAG & 2)
+          asm volatile("" :: "v"(ra[i][0]), "v"(ra[i][1]), "v"(ra[i][NAR - 1]));
+          continue;
+#endif
           if constexpr (AIN) {                       // planes arrive ready-made: three straight copies
             float* dst = a + (ld_row + i * RPP) * RS + st1_col;
             *reinterpret_cast<u32x4*>(dst) = ra[i][0];
@@ -493,8 +513,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
           *reinterpret_cast<u32x4*>(dst + 32) = t;
         }
 #pragma unroll
-      for (int j = 0; j < NBC; ++j)
+      for (int j = 0; j < NBC; ++j) {
+#if defined(VAM_DIAG) && (VAM_DIAG & 1)
+        asm volatile("" :: "v"(rb[j]));
+#else
         if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(b + b_loff[j]) = rb[j];
+#endif
+      }
     };
     const int a_row1 = (wm * TM * 32 + l31) * RS;
     const int b_row1 = (wn * TN * 32 + l31) * RS;
@@ -518,6 +543,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+#if defined(VAM_DIAG) && (VAM_DIAG & 4)
+            asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1]), "v"(fa[i][2]), "v"(fb[j][0]), "v"(fb[j][1]), "v"(fb[j][2]));
+            continue;
+#endif
             // fixed order, smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);

@@ -150,8 +150,10 @@ extern "C" int vam_win_attention(const float* qkv, int ld_qkv, float* out, int l
     hipLaunchKernelGGL((win_attn_kernel<8, 40>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, out, ld_out, table, B, H, W, C, heads, shift, scale);
   else if (ws == 4 && hd == 24)
     hipLaunchKernelGGL((win_attn_kernel<4, 24>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, out, ld_out, table, B, H, W, C, heads, shift, scale);
+  else if (ws == 4 && hd == 80)      // single-encoder / single-decoder models: the last attention block has M = 640 channels
+    hipLaunchKernelGGL((win_attn_kernel<4, 80>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, out, ld_out, table, B, H, W, C, heads, shift, scale);
   else {
-    set_error("vam_win_attention: unsupported (ws=%d, head_dim=%d); built for head_dim 24 and 40", ws, hd);
+    set_error("vam_win_attention: unsupported (ws=%d, head_dim=%d); built for head_dim 24, 40 and (ws 4) 80", ws, hd);
     return VAM_EINVAL;
   }
   return check_launch("win_attn_kernel");

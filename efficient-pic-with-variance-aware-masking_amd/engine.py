@@ -141,8 +141,12 @@ class Plan:
     def run(self):
         main = torch.cuda.current_stream(self.device)
         prof = ops.prof_on()
-        if self.n_events == 0:
+        if self.n_events == 0 or prof:
+            # (event profiler on: one stream, in recording order — a valid topological order — so that a launch's event
+            # pair brackets that launch alone and not whatever the other branch runs beside it)
             for c, s in zip(self.class_of, self.steps):
+                if isinstance(s, tuple):
+                    continue
                 if prof:
                     ops.prof_set_class(c)
                 s()
@@ -424,12 +428,14 @@ def lower_rem_blocks(plan: Plan, mods: Sequence[Ly.LatentRateReduction], y_cks: 
                      ep_bases: Sequence[Sequence[View]], ep_progs: Sequence[Sequence[View]], atts: Sequence[View],
                      outs: Sequence[Sequence[View]]):
     """K REM blocks in lockstep:  res = identity + enc(cat(f_latent, f_ent_base, f_ent_prog)) * att_mask
-    (layers/rem.py:130-141).  ep_progs[k] = [mu, sigma] windows (identity = their concat);
-    atts[k] = the N-channel mask, applied to both halves (rem_pic.py:194-195);
-    outs[k] = [mu', sigma'] windows."""
+    (layers/rem.py:130-141).  ep_progs[k] = [mu, sigma] windows with ``mu_std`` (identity = their concat), [sigma]
+    without; atts[k] = the N-channel mask, applied to every N-channel part (rem_pic.py:194-195);
+    outs[k] = [mu', sigma'] (or [sigma']) windows."""
     K = len(mods)
     m0 = mods[0]
-    assert all(m.mu_std for m in mods), "lowering is built for mu_std=True (README config)"
+    assert all(m.mu_std == m0.mu_std for m in mods)
+    parts = 2 if m0.mu_std else 1
+    assert all(len(e) == parts for e in ep_progs) and all(len(o) == parts for o in outs)
     names = ["enc_base_rep", "enc_progressive_entropy_params", "enc_base_entropy_params"]
     cur: List[Sequence[View]] = [[y] for y in y_cks] + [list(e) for e in ep_progs] + [list(e) for e in ep_bases]
     for d in range(len(m0.enc_base_rep)):
@@ -445,7 +451,7 @@ def lower_rem_blocks(plan: Plan, mods: Sequence[Ly.LatentRateReduction], y_cks: 
     probs = []
     for k in range(K):
         ret = t[k][0]
-        assert ret.C == 2 * N
+        assert ret.C == parts * N
         for half, (idv, o) in enumerate(zip(ep_progs[k], outs[k])):
             probs.append(ops.conv_problem(pk, [ret.window(half * N, N)], o, L.ACT_NONE, mul=atts[k], post=idv))
     plan.conv(probs)
@@ -646,7 +652,13 @@ def run_module(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         if isinstance(m, (Ly.Conv2d, Ly.SubpelConv)):
             o = lower_stacks(plan, [nn.Sequential(m)], [[v]], [None])[0]
         elif isinstance(m, Ly.ConvStack):
-            o = lower_stacks(plan, [m], [[v]], [None])[0]
+            c_head = getattr(m, "c_head", None)
+            if c_head is not None and m[0].in_channels > c_head and v.C == m[0].in_channels:
+                # slice stack called on cat(hyper, supports): same association of the first-layer sum as the fused plans
+                heads = lower_stack_heads(plan, [m], [v.window(0, c_head)], [True])
+                o = lower_stacks(plan, [m], [[v.window(c_head, v.C - c_head)]], [None], heads=heads)[0]
+            else:
+                o = lower_stacks(plan, [m], [[v]], [None])[0]
         elif isinstance(m, Ly.ConvTranspose2d):
             o = lower_deconv(plan, [m], [v], [None])[0]
         elif isinstance(m, Ly.GDN):

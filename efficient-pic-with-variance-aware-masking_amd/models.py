@@ -68,13 +68,20 @@ def define_hyperprior(multiple_hyperprior, M, N, dimensions_M):
     return h_a, h_mean_s, h_scale_s
 
 
-def _param_stack(cin):
-    """Five conv3x3 with GELU between: cin -> 224 -> 176 -> 128 -> 64 -> 32 (models/pic.py:83-164)."""
+def _param_stack(cin, c_head):
+    """Five conv3x3 with GELU between: cin -> 224 -> 176 -> 128 -> 64 -> 32 (models/pic.py:83-164).
+    ``c_head``: how many leading input channels are the hyperprior tensor (the rest are support slices).  The fused
+    plans compute the first layer as  conv(hyper; W[:, :c_head]) + conv(supports; W[:, c_head:])  (engine.lower_stack_heads);
+    a module-level call ``stack(torch.cat([hyper, *supports]))`` must associate the sum the same way, or the decoder of
+    the progressive container (module-level calls, test/functions_decode.py) would see a sigma that differs from the
+    encoder's (fused plan) in the last bit — enough to desynchronise the range coder."""
     widths = (cin, 224, 176, 128, 64, 32)
     mods = []
     for a, b in zip(widths[:-1], widths[1:]):
         mods += [Ly.conv(a, b, kernel_size=3, stride=1), Ly.GELU()]
-    return Ly.ConvStack(*mods[:-1])
+    st = Ly.ConvStack(*mods[:-1])
+    st.c_head = c_head
+    return st
 
 
 class CompressionModel(nn.Module):
@@ -135,12 +142,12 @@ class VarianceMaskingPIC(CompressionModel):
         self.g_s = define_decoder(multiple_decoder, N, M, division_dimension)
         self.h_a, self.h_mean_s, self.h_scale_s = define_hyperprior(multiple_hyperprior, M, N, division_dimension)
         nb, np_ = self.ns0, self.ns1 - self.ns0
-        self.cc_mean_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5)) for i in range(nb))
-        self.cc_scale_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5)) for i in range(nb))
-        self.lrp_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i + 1, 6)) for i in range(nb))
-        self.cc_mean_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1)) for i in range(np_))
-        self.cc_scale_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1)) for i in range(np_))
-        self.lrp_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 2, sp1 + 1)) for i in range(nb))
+        self.cc_mean_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5), d0) for i in range(nb))
+        self.cc_scale_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i, 5), d0) for i in range(nb))
+        self.lrp_transforms = nn.ModuleList(_param_stack(d0 + 32 * min(i + 1, 6), d0) for i in range(nb))
+        self.cc_mean_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1), delta) for i in range(np_))
+        self.cc_scale_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 1, sp1), delta) for i in range(np_))
+        self.lrp_transforms_prog = nn.ModuleList(_param_stack(delta + 32 * min(i + 2, sp1 + 1), delta) for i in range(nb))
         self._plans: Dict[tuple, "_FsqPlan"] = {}
         self._dec_plans: Dict[tuple, "_DecPlan"] = {}
         self.use_graph = True
@@ -244,13 +251,17 @@ class VarianceMaskingPIC(CompressionModel):
 
     # ---- the hot path
     def _check_config(self):
-        ok = (self.multiple_encoder and self.multiple_decoder and self.multiple_hyperprior and self.delta_encode
-              and self.total_mu_rep and self.all_scalable and self.dim_chunk == 32 and self.ns1 == 2 * self.ns0
-              and self.support_progressive_slices == 5)
-        if not ok:
-            raise NotImplementedError("the fused plan is built for the reference's README configuration "
-                                      "(dual encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable, "
-                                      "dim_chunk 32, division [d, 2d], 5 support slices)")
+        """What the lowering needs.  Every flag of models/__init__.py:11-55 is accepted (single or dual
+        encoder / decoder / hyperprior, any support_progressive_slices, delta_encode, total_mu_rep, all_scalable);
+        the slice geometry is the one the reference itself can run: 32-channel slices (the stacks end in 32 channels,
+        pic.py:83-164) and division [d, 2d] with M = 2d (the progressive stacks read latent_means[:, d:], whose width
+        must equal division[1] - division[0], pic.py:75,596-599)."""
+        if self.dim_chunk != 32 or self.ns1 != 2 * self.ns0 or self.M != 2 * self.division_dimension[0]:
+            raise NotImplementedError(f"slice geometry dim_chunk={self.dim_chunk}, division={self.division_dimension}, M={self.M}: "
+                                      "the channel-conditional stacks are built for 32-channel slices and division [d, 2d] "
+                                      "with M = 2d (as the reference's own stacks are, pic.py:83-164)")
+        if self.support_progressive_slices < 0:
+            raise ValueError("support_progressive_slices must be >= 0")
 
     def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False,
               train: bool = False, own_ck: bool = False) -> "_FsqPlan":
@@ -485,8 +496,6 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
         Ly._no_autograd(x)
         L.require_gpu()
         self._check_config()
-        if not self.mu_std:
-            raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
         nb = _max_images_per_plan(x)
         if x.shape[0] > nb:                            # tensors of one plan are addressed with 32-bit byte offsets
             return _cat_outputs([self.forward(x[i:i + nb], mask_pol, quality, False,
@@ -622,6 +631,23 @@ def _slice_stack_heads(plan, m, means_h, scales_h, which):
     return E.lower_stack_heads(plan, stacks, hyp, sup)
 
 
+def _lower_hyper_synthesis(plan, m, z_hat, base_only):
+    """compute_hyperprior's synthesis half (pic.py:285-298): with multiple_hyperprior two (mean, scale) pairs of d
+    channels each — only the first at quality 0 —, otherwise ONE pair with M channels whose halves feed the base and
+    the progressive stacks.  Returns (means_h, scales_h)."""
+    d = m.division_dimension[0]
+    B, hz, wz = z_hat.B, z_hat.H, z_hat.W
+    if m.multiple_hyperprior:
+        nh = 1 if base_only else 2
+        means_h, scales_h = plan.buf(B, 4 * hz, 4 * wz, nh * d), plan.buf(B, 4 * hz, 4 * wz, nh * d)
+        E.lower_stacks(plan, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)], [[z_hat]] * (2 * nh),
+                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
+    else:
+        means_h, scales_h = plan.buf(B, 4 * hz, 4 * wz, m.M), plan.buf(B, 4 * hz, 4 * wz, m.M)
+        E.lower_stacks(plan, [m.h_mean_s, m.h_scale_s], [[z_hat]] * 2, [means_h, scales_h])
+    return means_h, scales_h
+
+
 def _version_sig(mod: nn.Module):
     return tuple(p._version for p in mod.parameters())
 
@@ -680,7 +706,10 @@ class _FsqPlan:
                                   "vam_s2d_input"))
         y = self.y = plan.buf(B, h, w, 2 * d)
         plan.set_class("g_a")
-        E.lower_g_a(plan, [m.g_a[0], m.g_a[1]], x_s2d, [y.window(0, d), y.window(d, d)])
+        if m.multiple_encoder:
+            E.lower_g_a(plan, [m.g_a[0], m.g_a[1]], x_s2d, [y.window(0, d), y.window(d, d)])
+        else:                                            # one encoder with M output channels (builder.py:56-67)
+            E.lower_g_a(plan, [m.g_a], x_s2d, [y])
 
         # ---- hyperprior                                                            pic.py:278-298
         z = plan.buf(B, h // 4, w // 4, m.N)
@@ -695,13 +724,8 @@ class _FsqPlan:
         self.noise_y = plan.buf(B, h, w, d if base_only else 2 * d) if train else None
         plan.call(lambda: ops.eb_forward(z, m.entropy_bottleneck.packed_params(), self.z_hat, self.z_lik, ls_z, sym=self.z_sym,
                                          noise=self.noise_z))
-        nh = 1 if base_only else 2
-        means_h = plan.buf(B, h, w, nh * d)
-        scales_h = plan.buf(B, h, w, nh * d)
+        means_h, scales_h = _lower_hyper_synthesis(plan, m, self.z_hat, base_only)
         self.means_h, self.scales_h = means_h, scales_h
-        E.lower_stacks(plan, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)],
-                       [[self.z_hat]] * (2 * nh),
-                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
 
         # ---- base slices                                                           pic.py:522-554
         C = m.dim_chunk
@@ -756,15 +780,37 @@ class _FsqPlan:
         if base_only:
             if not symbols:                              # compress() does not decode (pic.py:671-860)
                 plan.set_class("g_s")
-                E.lower_g_s(plan, [m.g_s[0]], [yb], [self.x_hat])
+                E.lower_g_s(plan, [m.g_s[0] if m.multiple_decoder else m.g_s], [yb], [self.x_hat])
             return
 
         # ---- progressive slices                                                    pic.py:577-643
-        mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
         self.mu_p = plan.buf(B, h, w, d)
         self.std_p = plan.buf(B, h, w, d)
-        mu_tot = plan.buf(B, h, w, d)
+        # support vector of the mean chain: mu + y_hat_base with total_mu_rep (pic.py:601), else mu itself
+        mu_tot = plan.buf(B, h, w, d) if m.total_mu_rep else self.mu_p
         sp = m.support_progressive_slices
+        mu_std = getattr(m, "mu_std", True)
+        y_top = y.window(d, d)
+        y_sub = y.window(0, d) if m.delta_encode else None                        # pic.py:583-584
+        yp = self.y_prog = plan.buf(B, h, w, d)
+        g_s = m.g_s[1] if m.multiple_decoder else m.g_s
+        if train and not (m.all_scalable and mu_std):
+            raise NotImplementedError("training-mode plans are built for all_scalable=True, mu_std=True (README config)")
+
+        def supports(j):
+            """determine_support (pic.py:264-270): base slice j + the last min(sp, j) entries of the support vectors
+            (mu_total / std_total with all_scalable, the decoded progressive slices otherwise, pic.py:586-587)."""
+            s = min(sp, j)
+            sm, ss_ = (mu_tot, self.std_p) if m.all_scalable else (yp, yp)
+            return ([sl(yb, j)] + ([sl(sm, j - s, s)] if s else []), [sl(yb, j)] + ([sl(ss_, j - s, s)] if s else []))
+
+        if not m.all_scalable:
+            self._lower_prog_sequential(plan, heads, means_h, scales_h, hyper_done, supports, y_top, y_sub, yb, yp, ls_y,
+                                        table if indexes else None, symbols)
+            if not symbols:
+                plan.set_class("g_s")
+                E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
+            return
         msups, ssups = [], []
         # With all_scalable the progressive mu/sigma chain only needs y_hat_base[j] and its own history
         # (pic.py:586-612), so it runs on a second HIP stream concurrently with base slices > j.
@@ -775,14 +821,13 @@ class _FsqPlan:
         plan.set_class("slice_chain")
         for j in range(ns):
             plan.wait(base_done[j])
-            s = min(sp, j)
-            ms = [sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else [])          # supports; the hyperprior part is in `heads`
-            ss = [sl(yb, j)] + ([sl(self.std_p, j - s, s)] if s else [])
+            ms, ss = supports(j)                                               # the hyperprior part is in `heads`
             msups.append(ms)
             ssups.append(ss)
             E.lower_stacks(plan, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss],
                            [sl(self.mu_p, j), sl(self.std_p, j)], heads=heads)
-            plan.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)))       # pic.py:603
+            if m.total_mu_rep:
+                plan.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)))   # pic.py:601
         chain_done = plan.record()
         plan.branch(0)
         plan.wait(chain_done)
@@ -796,20 +841,20 @@ class _FsqPlan:
                 # at q <= check_levels[0] no REM applies): what ExtractChekpointRepr(x, q_ref) returns, pic.py:621-641
                 m_ck, rq_ck, junk = plan.buf(B, h, w, d), plan.buf(B, h, w, d), plan.buf(B, h, w, d)
                 plan.call(lambda: ops.variance_mask(self.std_p, self.ck_pr, m_ck, n_slice=ns))
-                plan.call(lambda: ops.gauss_tail(y.window(d, d), self.mu_p, self.std_p, y2=y.window(0, d), mask=m_ck,
-                                                 yhat=rq_ck, lik=junk))
+                plan.call(lambda: ops.gauss_tail(y_top, self.mu_p, self.std_p, y2=y_sub, mask=m_ck, yhat=rq_ck, lik=junk))
                 E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)],
                                [msups[j] + [sl(rq_ck, j)] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
                                [dict(act=L.ACT_HALF_TANH, post=sl(rq_ck, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)
             att = plan.buf(B, h, w, d)
             plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
-            mu_f, std_f = plan.buf(B, h, w, d), plan.buf(B, h, w, d)
+            std_f = plan.buf(B, h, w, d)
+            mu_f = plan.buf(B, h, w, d) if mu_std else self.mu_p      # without mu_std only sigma is refined (rem_pic.py:214-218)
             mods = [m.post_latent[rem_idx][j] for j in range(ns)]
             rem_io = ([sl(self.ck, j) for j in range(ns)],
                       [[sl(self.mu_b, j), sl(self.std_b, j)] for j in range(ns)],
-                      [[sl(self.mu_p, j), sl(self.std_p, j)] for j in range(ns)],
+                      [([sl(self.mu_p, j)] if mu_std else []) + [sl(self.std_p, j)] for j in range(ns)],
                       [sl(att, j) for j in range(ns)],
-                      [[sl(mu_f, j), sl(std_f, j)] for j in range(ns)])
+                      [([sl(mu_f, j)] if mu_std else []) + [sl(std_f, j)] for j in range(ns)])
             if train:
                 self.rem_params = [p for mod in mods for p in mod.parameters()]
                 self.packs = E.TrainPacks(*E.rem_trained_convs(mods))
@@ -825,11 +870,11 @@ class _FsqPlan:
         plan.keep.append(self.thr)
         plan.call(lambda: ops.variance_mask(std_f, self.pr, self.mask, n_slice=ns, thr=self.thr))   # pic.py:621-622
         rq = plan.buf(B, h, w, d)
-        plan.call(lambda: ops.gauss_tail(y.window(d, d), mu_f, std_f, y2=y.window(0, d), mask=self.mask, yhat=rq,
+        plan.call(lambda: ops.gauss_tail(y_top, mu_f, std_f, y2=y_sub, mask=self.mask, yhat=rq,
                                          lik=self.lik.window(d, d), log2sum=ls_y,
                                          sym=self.sym.window(d, d) if symbols else None))           # pic.py:625-629
         if train:
-            yr, y0, nz = y.window(d, d), y.window(0, d), self.noise_y.window(d, d)
+            yr, y0, nz = y_top, y_sub, self.noise_y.window(d, d)
             plan.call(lambda: ops.gauss_train(yr, mu_f, std_f, nz, y2=y0, mask=self.mask, lik=self.lik.window(d, d)))
             if rem_idx is not None:
                 # ---- backward plan: dL/dlik (progressive half) -> (dmu', dsigma') -> REM parameters
@@ -850,13 +895,54 @@ class _FsqPlan:
                                      rem_io[3], self.packs, grads)
         if indexes:                                                                   # pic.py:813
             plan.call(lambda: ops.build_indexes(std_f, table, mask=self.mask, out=self.idx.window(d, d)))
-        yp = self.y_prog = plan.buf(B, h, w, d)
         E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
                        [sl(yp, j) for j in range(ns)],
                        [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
         if not symbols:
             plan.set_class("g_s")
-            E.lower_g_s(plan, [m.g_s[1]], [yp], [self.x_hat])
+            E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
+
+    def _lower_prog_sequential(self, plan, heads, means_h, scales_h, hyper_done, supports, y_top, y_sub, yb, yp, ls_y,
+                               table, symbols):
+        """all_scalable = False (pic.py:586-587): the (mu, sigma) stacks of progressive slice j read the DECODED
+        progressive slices j-sp..j-1, so mask, quantisation and LRP of a slice must finish before the next slice's
+        stacks start — one slice at a time, on the caller's stream."""
+        m, C, ns = self.m, self.m.dim_chunk, self.m.ns0
+        B, h, w, d = self.B, self.H // 16, self.W // 16, self.m.division_dimension[0]
+        sl = lambda v, i, n=1: v.window(i * C, n * C)
+        mu_std = getattr(m, "mu_std", True)
+        rem_idx = self.rem_idx
+        plan.set_class("stack_heads")
+        heads.update(_slice_stack_heads(plan, m, means_h, scales_h, "prog"))
+        plan.set_class("slice_chain")
+        self.mask = plan.buf(B, h, w, d)
+        self.thr = None                                   # per-slice launches: thresholds are not collected
+        rq = plan.buf(B, h, w, d)
+        mu_f, std_f = self.mu_p, self.std_p
+        if rem_idx is not None:
+            self.ck = plan.buf(B, h, w, d)
+            att = plan.buf(B, h, w, d)
+            std_f = plan.buf(B, h, w, d)
+            mu_f = plan.buf(B, h, w, d) if mu_std else self.mu_p
+            self.rem_sig = _version_sig(m.post_latent[rem_idx])
+        self.mu_f, self.std_f = mu_f, std_f
+        for j in range(ns):
+            ms, ss = supports(j)
+            E.lower_stacks(plan, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss],
+                           [sl(self.mu_p, j), sl(self.std_p, j)], heads=heads)
+            if rem_idx is not None:                                                   # rem_pic.py:363-377
+                plan.call(lambda j=j: ops.variance_mask(sl(self.std_p, j), self.pr, sl(att, j), n_slice=1))
+                E.lower_rem_blocks(plan, [m.post_latent[rem_idx][j]], [sl(self.ck, j)], [[sl(self.mu_b, j), sl(self.std_b, j)]],
+                                   [([sl(self.mu_p, j)] if mu_std else []) + [sl(self.std_p, j)]], [sl(att, j)],
+                                   [([sl(mu_f, j)] if mu_std else []) + [sl(std_f, j)]])
+            plan.call(lambda j=j: ops.variance_mask(sl(std_f, j), self.pr, sl(self.mask, j), n_slice=1))          # pic.py:621-622
+            plan.call(lambda j=j: ops.gauss_tail(sl(y_top, j), sl(mu_f, j), sl(std_f, j), y2=sl(y_sub, j) if y_sub is not None else None,
+                                                 mask=sl(self.mask, j), yhat=sl(rq, j), lik=sl(self.lik, ns + j), log2sum=ls_y,
+                                                 sym=sl(self.sym, ns + j) if symbols else None))                  # pic.py:625-629
+            if table is not None:
+                plan.call(lambda j=j: ops.build_indexes(sl(std_f, j), table, mask=sl(self.mask, j), out=sl(self.idx, ns + j)))
+            E.lower_stacks(plan, [m.lrp_transforms_prog[j]], [ms + [sl(rq, j)]], [sl(yp, j)],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))], heads=heads)              # pic.py:635-641
 
     # -------------------------------------------------------------------------------------------
     def set_noise(self, noise=None):
@@ -972,12 +1058,9 @@ class _DecPlan:
         med = nv(m.N, hz, wz)
         med.buf.copy_(m.entropy_bottleneck._get_medians().detach().reshape(1, 1, 1, -1).expand_as(med.buf))
         z_hat = nv(m.N, hz, wz)
-        nh = 1 if base_only else 2
-        means_h, scales_h = nv(nh * d), nv(nh * d)
         P = self.p_hyper = E.Plan(device)
         P.call(lambda: ops.dequantize(self.z_sym, med, z_hat))                       # entropy_models.py:520-525
-        E.lower_stacks(P, [m.h_mean_s[k] for k in range(nh)] + [m.h_scale_s[k] for k in range(nh)], [[z_hat]] * (2 * nh),
-                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
+        means_h, scales_h = _lower_hyper_synthesis(P, m, z_hat, base_only)
         heads = _slice_stack_heads(P, m, means_h, scales_h, "base")                 # same association as the encoder's plan
         if not base_only:
             heads.update(_slice_stack_heads(P, m, means_h, scales_h, "prog"))
@@ -998,12 +1081,14 @@ class _DecPlan:
             self.p_base.append((Pa, Pb))
         self.p_syn = E.Plan(device)
         if base_only:
-            E.lower_g_s(self.p_syn, [m.g_s[0]], [yb], [self.x_hat])
+            E.lower_g_s(self.p_syn, [m.g_s[0] if m.multiple_decoder else m.g_s], [yb], [self.x_hat])
             return
         # ---- progressive slices
-        mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
-        mu_p, std_p, mu_tot, mask, rq, yp = nv(d), nv(d), nv(d), nv(d), nv(d), nv(d)
-        mu_f, std_f = (nv(d), nv(d)) if rem_idx is not None else (mu_p, std_p)
+        mu_p, std_p, mask, rq, yp = nv(d), nv(d), nv(d), nv(d), nv(d)
+        mu_tot = nv(d) if m.total_mu_rep else mu_p                                    # pic.py:601
+        mu_std = getattr(m, "mu_std", True)
+        std_f = nv(d) if rem_idx is not None else std_p
+        mu_f = nv(d) if (rem_idx is not None and mu_std) else mu_p
         self.ck = nv(d) if rem_idx is not None else None
         att = nv(d) if rem_idx is not None else None
         self.idx_p, self.sym_p = ni(d), ni(d)
@@ -1011,23 +1096,26 @@ class _DecPlan:
         self.p_prog = []
         for j in range(ns):
             s_ = min(sp, j)
-            ms = [sl(yb, j)] + ([sl(mu_tot, j - s_, s_)] if s_ else [])
-            ss = [sl(yb, j)] + ([sl(std_p, j - s_, s_)] if s_ else [])
+            sm, ss_v = (mu_tot, std_p) if m.all_scalable else (yp, yp)                # pic.py:586-587
+            ms = [sl(yb, j)] + ([sl(sm, j - s_, s_)] if s_ else [])
+            ss = [sl(yb, j)] + ([sl(ss_v, j - s_, s_)] if s_ else [])
             Pa, Pb = E.Plan(device), E.Plan(device)
             E.lower_stacks(Pa, [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]], [ms, ss], [sl(mu_p, j), sl(std_p, j)],
                            heads=heads)
-            Pa.call(lambda j=j: ops.add(sl(mu_p, j), sl(yb, j), sl(mu_tot, j)))
+            if m.total_mu_rep:
+                Pa.call(lambda j=j: ops.add(sl(mu_p, j), sl(yb, j), sl(mu_tot, j)))
             if rem_idx is not None:
                 Pa.call(lambda j=j: ops.variance_mask(sl(std_p, j), self.pr, sl(att, j), n_slice=1))
                 E.lower_rem_blocks(Pa, [m.post_latent[rem_idx][j]], [sl(self.ck, j)], [[sl(mu_b, j), sl(std_b, j)]],
-                                   [[sl(mu_p, j), sl(std_p, j)]], [sl(att, j)], [[sl(mu_f, j), sl(std_f, j)]])
+                                   [([sl(mu_p, j)] if mu_std else []) + [sl(std_p, j)]], [sl(att, j)],
+                                   [([sl(mu_f, j)] if mu_std else []) + [sl(std_f, j)]])
             Pa.call(lambda j=j: ops.variance_mask(sl(std_f, j), self.pr, sl(mask, j), n_slice=1))       # pic.py:942
             Pa.call(lambda j=j: ops.build_indexes(sl(std_f, j), table, mask=sl(mask, j), out=sl(self.idx_p, j)))  # :945
             Pb.call(lambda j=j: ops.dequantize(sl(self.sym_p, j), sl(mu_f, j), sl(rq, j)))               # :948
             E.lower_stacks(Pb, [m.lrp_transforms_prog[j]], [ms + [sl(rq, j)]], [sl(yp, j)],
                            [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))], heads=heads)
             self.p_prog.append((Pa, Pb))
-        E.lower_g_s(self.p_syn, [m.g_s[1]], [yp], [self.x_hat])
+        E.lower_g_s(self.p_syn, [m.g_s[1] if m.multiple_decoder else m.g_s], [yp], [self.x_hat])
 
     def _decode_slice(self, strings, idx_view: ops.IView, sym_view: ops.IView, tables, C):
         """indexes GPU -> host, rANS decode per image, symbols host -> GPU (NHWC window)."""

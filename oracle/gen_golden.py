@@ -31,6 +31,24 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
 
 
+# constructor flags away from the README configuration (section 9); shared with the tests through vampic.synth? no —
+# the tests carry the same table (tests/config_variants.py) and check it against the fixture's key set
+CONFIG_VARIANTS = {
+    "single_encoder": dict(multiple_encoder=False),
+    "single_decoder": dict(multiple_decoder=False),
+    "single_hyperprior": dict(multiple_hyperprior=False),
+    "all_single": dict(multiple_encoder=False, multiple_decoder=False, multiple_hyperprior=False),
+    "sp0": dict(support_progressive_slices=0),
+    "sp2": dict(support_progressive_slices=2),
+    "sp8": dict(support_progressive_slices=8),
+    "no_delta_no_mu_rep": dict(delta_encode=False, total_mu_rep=False),
+    "not_all_scalable": dict(all_scalable=False),
+    "rem_big": dict(model="rem", dimension="big"),
+    "rem_no_mu_std": dict(model="rem", mu_std=False),
+    "rem_not_all_scalable": dict(model="rem", all_scalable=False, support_progressive_slices=3),
+}
+
+
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
@@ -251,6 +269,33 @@ def main():
             scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
     np.savez_compressed(os.path.join(GOLD, "demo_256.npz"), **rec)
     with open(os.path.join(GOLD, "demo_256.json"), "w") as f:
+        json.dump(scal, f, indent=1)
+
+    # 9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each
+    #    (q = 0 and q = 2.5; REM variants with a checkpoint latent at their first check level).  Weights: the same
+    #    name-keyed synthetic generator, so the shared modules carry the same values in every variant.
+    rec, scal = {}, {}
+    x = synth.synth_image(1, 64, 64, seed=2)
+    for name, over in CONFIG_VARIANTS.items():
+        a_ = argparse.Namespace(**{**vars(args), "model": "pic", **over})
+        ref_net = quiet(get_model, a_, "cpu").eval()
+        fill(ref_net, 0)
+        with torch.no_grad():
+            ck = None
+            if a_.model == "rem":
+                ck = ref_net.forward_single_quality(x, quality=a_.check_levels[0], training=False)["y_hat"]
+                rec[f"{name}_ck"] = ck.numpy()
+            for q in (0, 2.5):
+                kw = dict(checkpoint_ref=ck.clone()) if (ck is not None and q > 0) else {}
+                o = ref_net.forward_single_quality(x, quality=q, training=False, **kw)
+                tag = f"{name}_q{q}"
+                rec[tag + "_x_hat"] = o["x_hat"][:, :, ::2, ::2].numpy()
+                rec[tag + "_y_hat"] = o["y_hat"].numpy()
+                mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
+                bits = sum(torch.log(v.double()).sum().item() for v in o["likelihoods"].values()) / (-np.log(2) * 64 * 64)
+                scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
+    np.savez_compressed(os.path.join(GOLD, "config_variants.npz"), **rec)
+    with open(os.path.join(GOLD, "config_variants.json"), "w") as f:
         json.dump(scal, f, indent=1)
 
     print("golden vectors written to", GOLD)

@@ -368,14 +368,17 @@ def rem_block(sd: SD, pre: str, y_ck: Tensor, ep_base: Tensor, ep_prog: Tensor, 
 # --------------------------------------------------------------------------
 # model data flow  (models/pic.py:278-298, 497-666; models/rem_pic.py:142-220, 229-422)
 # --------------------------------------------------------------------------
-def compute_hyperprior(sd: SD, y: Tensor, quality: float):
+def compute_hyperprior(sd: SD, y: Tensor, quality: float, multiple_hyperprior: bool = True):
+    """models/pic.py:278-298."""
     z = h_a(sd, y)
     z_hat, z_lik = eb_forward(sd, z)
+    if not multiple_hyperprior:                       # one synthesis pair with M output channels
+        return h_s(sd, "h_mean_s.", z_hat), h_s(sd, "h_scale_s.", z_hat), z_lik, z_hat
     if quality == 0:
         return h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_scale_s.0.", z_hat), z_lik, z_hat
-    mean = torch.cat([h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_mean_s.1.", z_hat)], 1)
-    scl = torch.cat([h_s(sd, "h_scale_s.0.", z_hat), h_s(sd, "h_scale_s.1.", z_hat)], 1)
-    return mean, scl, z_lik, z_hat
+    means = torch.cat([h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_mean_s.1.", z_hat)], 1)
+    scales = torch.cat([h_s(sd, "h_scale_s.0.", z_hat), h_s(sd, "h_scale_s.1.", z_hat)], 1)
+    return means, scales, z_lik, z_hat
 
 
 def find_check_quality(check_levels: Sequence[float], quality: float):
@@ -410,16 +413,21 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
                            max_support: int = 5, prog_support: int = 5,
                            checkpoint_ref: Optional[Tensor] = None,
                            check_levels: Optional[Sequence[float]] = None,
-                           mu_std: bool = True) -> dict:
+                           mu_std: bool = True, multiple_encoder: bool = True, multiple_decoder: bool = True,
+                           multiple_hyperprior: bool = True, delta_encode: bool = True, total_mu_rep: bool = True,
+                           all_scalable: bool = True) -> dict:
     """``VarianceMaskingPIC.forward_single_quality`` (models/pic.py:497-666) and, when
     ``check_levels`` is given, ``VarianceMaskingPICREM.forward`` in eval mode
-    (models/rem_pic.py:229-422).  All flags of the README config are on
-    (multiple encoder/decoder/hyperprior, delta_encode, total_mu_rep, all_scalable).
+    (models/rem_pic.py:229-422).  The keyword flags are the constructor's (models/__init__.py:11-55,
+    pic.py:27-42); their defaults are the README configuration.
     """
     rem = check_levels is not None
     with torch.no_grad():
-        y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)
-        means_h, scales_h, z_lik, z_hat = compute_hyperprior(sd, y, quality)
+        if multiple_encoder:                                              # pic.py:501-508
+            y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)
+        else:
+            y = g_a(sd, "g_a.", x)
+        means_h, scales_h, z_lik, z_hat = compute_hyperprior(sd, y, quality, multiple_hyperprior)
         ns0 = div // chunk
         ys = y.chunk(y.shape[1] // chunk, 1)
         yhat_b: List[Tensor] = []
@@ -439,21 +447,25 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
             yhat_b.append(yh + 0.5 * torch.tanh(lrp))
         y_base = torch.cat(yhat_b, 1)
         if quality == 0:
-            x_hat = g_s(sd, "g_s.0.", y_base).clamp(0, 1)
+            x_hat = g_s(sd, "g_s.0." if multiple_decoder else "g_s.", y_base).clamp(0, 1)
             return {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
                     "y_hat": y_base, "y_base": y_base, "mu_base": torch.cat(mu_b, 1),
                     "std_base": torch.cat(std_b, 1), "z_hat": z_hat, "y": y}
 
         ck = checkpoint_ref.chunk(10, 1) if checkpoint_ref is not None else None
         mu_tot, std_tot, mu_p, std_p, masks, yhat_p = [], [], [], [], [], []
-        for j in range(ns0):
-            r = ys[ns0 + j] - ys[j]
-            s = min(prog_support, j)
-            msup = torch.cat([means_h[:, div:], yhat_b[j]] + mu_tot[j - s:j], 1)
-            ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + std_tot[j - s:j], 1)
+        n_prog = y.shape[1] // chunk - ns0
+        for j in range(n_prog):
+            r = ys[ns0 + j] - ys[j] if delta_encode else ys[ns0 + j]      # pic.py:583-584
+            # determine_support (pic.py:264-270): base slice j + the last min(sp, j) entries of the support vectors
+            s = 0 if prog_support == 0 else min(prog_support, j)
+            sv_m = mu_tot if all_scalable else yhat_p                     # pic.py:586-587
+            sv_s = std_tot if all_scalable else yhat_p
+            msup = torch.cat([means_h[:, div:], yhat_b[j]] + sv_m[j - s:j], 1)
+            ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + sv_s[j - s:j], 1)
             mu = cc_stack(sd, f"cc_mean_transforms_prog.{j}.", msup)
             sc = cc_stack(sd, f"cc_scale_transforms_prog.{j}.", ssup)
-            mu_tot.append(mu + yhat_b[j])
+            mu_tot.append(mu + yhat_b[j] if total_mu_rep else mu)         # pic.py:601
             std_tot.append(sc)
             if rem and ck is not None and quality > check_levels[0]:
                 att = variance_mask(sc, quality)                      # rem_pic.py:185-192
@@ -477,7 +489,7 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
             rh = rh + 0.5 * torch.tanh(lrp)
             yhat_p.append(rh + yhat_b[j])
         y_prog = torch.cat(yhat_p, 1)
-        x_hat = g_s(sd, "g_s.1.", y_prog).clamp(0, 1)
+        x_hat = g_s(sd, "g_s.1." if multiple_decoder else "g_s.", y_prog).clamp(0, 1)
         return {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
                 "y_hat": y_prog, "y_base": y_base, "y_prog": y_prog,
                 "mu_base": torch.cat(mu_b, 1), "mu": torch.cat(mu_p, 1),

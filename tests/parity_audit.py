@@ -30,7 +30,7 @@ THRESH_TOL = 2e-4        # relative distance of the oracle's sigma from the quan
 
 
 def audit(y_gpu: torch.Tensor, out: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], q: float, *,
-          div: int = 320, chunk: int = 32, max_support: int = 5) -> dict:
+          div: int = 320, chunk: int = 32, max_support: int = 5, all_scalable: bool = True, delta_encode: bool = True) -> dict:
     """``y_gpu``: the HIP path's latent y [B, 2*div, h, w]; ``out``: its output dict (cpu tensors); ``ref``: the oracle's
     dict (holds "y").  Returns counts plus ``violations`` (list of strings; empty = every difference is explained)."""
     ns = div // chunk
@@ -69,9 +69,10 @@ def audit(y_gpu: torch.Tensor, out: Dict[str, torch.Tensor], ref: Dict[str, torc
     if "mask" not in ref:
         return rep
     # ---- progressive slices
+    prog_flipped = False
     for j in range(ns):
-        r_g = sl(yg, ns + j) - sl(yg, j)
-        r_o = sl(yo, ns + j) - sl(yo, j)
+        r_g = sl(yg, ns + j) - sl(yg, j) if delta_encode else sl(yg, ns + j)
+        r_o = sl(yo, ns + j) - sl(yo, j) if delta_encode else sl(yo, ns + j)
         m_g, m_o = sl(out["mask"], j), sl(ref["mask"], j)
         s_o = sl(ref["std"], j)
         mdiff = m_g != m_o
@@ -84,6 +85,9 @@ def audit(y_gpu: torch.Tensor, out: Dict[str, torch.Tensor], ref: Dict[str, torc
         if (nm or nsym) and rep["first"] is None:
             rep["first"] = f"prog {j}"
         tainted = any(flipped_b[k] for k in range(j + 1))
+        if not all_scalable:          # pic.py:586-587: the (mu, sigma) stacks read the decoded progressive slices before j
+            tainted = tainted or prog_flipped
+            prog_flipped = prog_flipped or bool(nm or nsym)
         if tainted:
             rep["downstream"] += nm + nsym
             continue

@@ -1,0 +1,77 @@
+"""Every constructor flag of the reference's factory (models/__init__.py:11-55) away from the README values runs through
+the HIP plan: forward_single_quality against the oracle and the vectors the REFERENCE produced
+(tests/golden/config_variants.*), and the real codec (compress -> decompress) against the likelihood path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vampic                      # noqa: E402
+import vampic.synth as synth       # noqa: E402
+import vampic_oracle as O          # noqa: E402
+from config_variants import CONFIG_VARIANTS, variant_args, oracle_kwargs     # noqa: E402
+from parity_audit import audit     # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _latent(net, B, H, W, base_only, rem_idx):
+    for k, p in net._plans.items():
+        if k[:5] == (B, H, W, base_only, rem_idx) and len(k) == 6:
+            return p.y.torch_nchw().cpu()
+    raise KeyError
+
+
+@pytest.mark.parametrize("name", list(CONFIG_VARIANTS))
+def test_config_variant_matches_reference(name):
+    a = variant_args(name)
+    net = vampic.get_model(a, "cpu").eval()
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    torch.nn.Module.load_state_dict(net, sd)
+    net = net.cuda()
+    gold = np.load(os.path.join(GOLD, "config_variants.npz"))
+    scal = json.load(open(os.path.join(GOLD, "config_variants.json")))
+    kw = oracle_kwargs(a)
+    x = synth.synth_image(1, 64, 64, seed=2)
+    ck = torch.from_numpy(gold[f"{name}_ck"]) if a.model == "rem" else None
+    for q in (0, 2.5):
+        tag = f"{name}_q{q}"
+        use_ck = ck is not None and q > 0
+        with torch.no_grad():
+            if a.model == "rem":
+                out = net.forward_single_quality(x.cuda(), q, training=False, checkpoint_ref=ck.cuda() if use_ck else None)
+            else:
+                out = net.forward_single_quality(x.cuda(), q)
+        ref = O.forward_single_quality(sd, x, q, checkpoint_ref=ck if use_ck else None, **kw)
+        cpu = {k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}
+        rem_idx = 0 if use_ck else None
+        aud = audit(_latent(net, 1, 64, 64, q == 0, rem_idx), cpu, ref, q, all_scalable=a.all_scalable,
+                    delta_encode=a.delta_encode)
+        if not use_ck:                       # (with a REM the attention mask is a second, unaudited threshold decision)
+            assert aud["violations"] == [], (tag, aud)
+        if aud["sym_flips"] == 0 and aud["mask_flips"] == 0:
+            assert (cpu["y_hat"] - torch.from_numpy(gold[tag + "_y_hat"])).abs().max().item() <= 2e-4 * 60, tag
+            assert np.abs(cpu["x_hat"][:, :, ::2, ::2].numpy() - gold[tag + "_x_hat"]).max() <= 1e-4, tag
+            mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
+            assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
+            bpp = -cpu["log2_likelihood_sum"].sum().item() / 4096
+            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
+        else:
+            print("boundary hit", tag, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
+            assert aud["sym_flips"] <= 0.05 * cpu["y_hat"].numel()
+            assert np.abs(cpu["x_hat"][:, :, ::2, ::2].numpy() - gold[tag + "_x_hat"]).max() <= 0.5
+    # the real codec of this variant: the decoder must reproduce the encoder's decisions bit for bit
+    net.update()
+    with torch.no_grad():
+        for q in (0, 2.5):
+            use_ck = ck is not None and q > 0
+            kwq = dict(checkpoint_rep=ck.cuda()) if use_ck else {}
+            fw = (net.forward_single_quality(x.cuda(), q, training=False, checkpoint_ref=ck.cuda() if use_ck else None)
+                  if a.model == "rem" else net.forward_single_quality(x.cuda(), q))
+            enc = net.compress(x.cuda(), quality=q, **kwq)
+            dec = net.decompress(enc["strings"], enc["shape"], quality=q, **kwq)
+            assert torch.equal(dec["x_hat"], fw["x_hat"]), (name, q)

@@ -196,3 +196,32 @@ def test_oracle_reproduces_reference_demo_image_256(synth_model_cpu):
             assert np.array_equal(thr, gold[tag + "_thr"]), tag
         assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4
         assert abs(O.bpp(o["likelihoods"], 65536) - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"])
+
+
+def test_oracle_reproduces_reference_config_variants():
+    """Every constructor flag away from the README values (single encoder / decoder / hyperprior, support slices 0 / 2 / 8,
+    delta_encode / total_mu_rep / all_scalable off, REM dimension "big", mu_std off): the oracle, fed the state_dict of
+    THIS package's model for that variant (same keys as the reference's or the lookup fails), against the vectors the
+    REFERENCE produced (oracle/gen_golden.py section 9)."""
+    import vampic
+    from config_variants import CONFIG_VARIANTS, variant_args, oracle_kwargs
+    gold = np.load(os.path.join(GOLD, "config_variants.npz"))
+    scal = json.load(open(os.path.join(GOLD, "config_variants.json")))
+    x = synth.synth_image(1, 64, 64, seed=2)
+    assert {k.rsplit("_q", 1)[0] for k in scal} == set(CONFIG_VARIANTS)
+    for name in CONFIG_VARIANTS:
+        a = variant_args(name)
+        net = vampic.get_model(a, "cpu")
+        sd = synth.synth_state_dict(net.state_dict(), seed=0)
+        kw = oracle_kwargs(a)
+        ck = None
+        if a.model == "rem":
+            ck = O.forward_single_quality(sd, x, a.check_levels[0], **kw)["y_hat"]
+            _close(ck, gold[f"{name}_ck"], 2e-5)
+        for q in (0, 2.5):
+            o = O.forward_single_quality(sd, x, q, checkpoint_ref=(ck if q > 0 else None), **kw)
+            tag = f"{name}_q{q}"
+            _close(o["y_hat"], gold[tag + "_y_hat"], 2e-5)
+            _close(o["x_hat"][:, :, ::2, ::2], gold[tag + "_x_hat"], 2e-5)
+            assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4, tag
+            assert abs(O.bpp(o["likelihoods"], 4096) - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), tag
