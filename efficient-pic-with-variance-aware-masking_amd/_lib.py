@@ -91,6 +91,7 @@ _SIGNATURES = {
     "vam_gauss_tail": (C.c_int, [C.c_void_p, C.c_int] * 5 + [C.c_void_p, C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_build_indexes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_eb_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p]),
+    "vam_eb_aux_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vam_dequantize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

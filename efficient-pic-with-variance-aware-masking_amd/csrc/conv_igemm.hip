@@ -94,9 +94,17 @@ constexpr int PK = 16;  // packing granularity of the weight buffer along K
 // planes ("P3": [pixel][8-channel group][plane 3][8 bf16], 48 B per group) by the producing launch's epilogue
 // (VAM_CONV_OUT_BF3) — the staging is then a pure copy, like the weights'.  Inside conv stacks every intermediate is
 // consumed by exactly one convolution, which otherwise re-splits each element once per tap and per N tile.
-template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0>
-__global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const GroupArgs args) {
-  constexpr int NT = WGM * WGN * 64;         // threads per block
+// SPEC (MODE 1 only): wave-specialised block of 2 x WGM x WGN waves.  Waves 0..NW-1 ("consumers") do nothing but operand
+// reads and MFMAs; waves NW..2NW-1 ("loaders") do nothing but global loads, the bf16x3 split and the LDS stores, two
+// K chunks ahead, into a double-buffered LDS tile.  A workgroup's waves are dealt to the 4 SIMDs cyclically, so every
+// SIMD hosts one consumer and one loader: the matrix pipe and the vector / memory pipes run side by side instead of
+// taking turns inside each wave (measured on the 128x192 tile: MFMA-only time 1.42 ms, staging-only 1.03 ms, the
+// un-specialised kernel 2.45 ms = their SUM).  One s_barrier per K chunk.
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
+__global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <= 192) ? 4 : 2) : 2) void conv_igemm_kernel(const GroupArgs args) {
+  static_assert(SPEC == 0 || MODE == 1, "wave specialisation is built for the split-operand mode");
+  constexpr int NT = WGM * WGN * 64;         // threads of one role group (= threads per block without SPEC)
+  constexpr int NTB = NT * (SPEC ? 2 : 1);   // threads per block
   constexpr int LDS_LD = BK;                 // floats per LDS row: no padding, the 16-byte chunks of a row are
                                              // XOR-swizzled instead (below) so that both the staging writes and
                                              // the MFMA operand reads are bank-conflict free
@@ -156,7 +164,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const int tn = t % P.tiles_n, tm = t / P.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int tid = threadIdx.x;
+  // SPEC: tid indexes a thread inside its role group (consumers 0..NT-1, loaders 0..NT-1)
+  const bool is_loader = SPEC && (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= WGM * WGN);
+  const int tid = (SPEC && (int)threadIdx.x >= NT) ? (int)threadIdx.x - NT : (int)threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
   const int ld_row = tid / CPR;              // row within a pass
@@ -186,12 +196,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     }
   }
   f32x16 acc[TM][TN];
+  if constexpr (!SPEC) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   const int l31 = lane & 31, lh = lane >> 5;
   const unsigned long long wpa = reinterpret_cast<unsigned long long>(P.wpack);
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
     //   and 2s+1 from lanes 32-63.  With the XOR term both the staging writes (16 lanes = 4 rows x 4 groups of one
     //   plane) and the operand reads (16 rows of one chunk) touch every LDS bank exactly once.
     constexpr int RS = 48;
-    constexpr int NBUF = (BM + BN <= 128) ? 2 : 1;   // LDS buffers: 1.5x the bytes of fp32 rows, so wide tiles single-buffer
+    constexpr int NBUF = SPEC ? 2 : ((BM + BN <= 128) ? 2 : 1);   // LDS buffers: 1.5x the bytes of fp32 rows, so wide tiles single-buffer (wave-specialised blocks always double-buffer)
     constexpr int NBC = (BN * 12 + NT - 1) / NT;     // 16-byte weight chunks per thread and K chunk
     float* sA1 = smem;                               // [NBUF][BM][RS]
     float* sB1 = smem + NBUF * BM * RS;              // [NBUF][BN][RS]
@@ -557,7 +569,55 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
           }
       }
     };
-    if constexpr (NBUF == 2) {
+    if constexpr (SPEC) {
+      // chunk c sits in register stage c & 1 between its global loads and its LDS store, and in LDS buffer c & 1
+      // afterwards.  Iteration ch: consumers compute from buffer ch & 1 while loaders store chunk ch+1 into the other
+      // buffer (its last readers passed the barrier that ended iteration ch-1) and request chunk ch+3.  Both roles run
+      // the same number of barriers.
+      if (is_loader) {
+        gload(ra0, rb0);
+        if (n_chunks > 1) gload(ra1, rb1);
+        sstore(0, ra0, rb0);
+        if (n_chunks > 2) gload(ra0, rb0);
+        __syncthreads();
+        for (int ch = 0; ch < n_chunks; ch += 2) {
+          if (ch + 1 < n_chunks) sstore(1, ra1, rb1);
+          if (ch + 3 < n_chunks) gload(ra1, rb1);
+          __syncthreads();
+          if (ch + 1 >= n_chunks) break;
+          if (ch + 2 < n_chunks) sstore(0, ra0, rb0);
+          if (ch + 4 < n_chunks) gload(ra0, rb0);
+          __syncthreads();
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        for (int ch = 0; ch < n_chunks; ch += 2) {
+          compute(0);
+          __syncthreads();
+          if (ch + 1 >= n_chunks) break;
+          compute(1);
+          __syncthreads();
+        }
+        // the whole C tile goes to LDS (it fits in the pipeline buffers, which every wave has left behind the last
+        // barrier); C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        float* sCf = smem;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              sCf[row * (BN + 4) + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+            }
+      }
+    } else if constexpr (NBUF == 2) {
       // one barrier per chunk; at the top of step ch: LDS[ch&1] = chunk ch, stage (ch+1)&1 = chunk ch+1 (requested two
       // steps ago), stage ch&1 = chunk ch+2 (requested one step ago)
       gload(ra0, rb0);
@@ -598,9 +658,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   // streamed out with one float4 of 4 consecutive channels per lane: 16-byte aux loads and
   // stores, and the activation code exists once instead of once per accumulator register.
   constexpr int LDC = BN + 4;
-  constexpr int SROWS = WGM * 32;            // rows per slab
+  constexpr int SROWS = SPEC ? BM : WGM * 32;   // rows of C held in LDS at a time (SPEC: the whole tile)
   float* sC = smem;  // the pipeline buffers are dead after the last barrier of the loop
-  int* sPix = reinterpret_cast<int*>(smem + SROWS * LDC);   // per slab row: output pixel index, batch index
+  int* sPix = reinterpret_cast<int*>(smem + SROWS * LDC);   // per LDS row: output pixel index, batch index
   const bool ps2 = (P.flags & VAM_CONV_PS2) != 0;
   const bool nchw = (P.flags & VAM_CONV_OUT_NCHW) != 0;
   const bool dense = !ps2 && !nchw && P.osy == 1 && P.osx == 1 && P.ooy == 0 && P.oox == 0 &&
@@ -609,113 +669,124 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void conv_igemm_kernel(const Gro
   const bool out_p3 = (P.flags & VAM_CONV_OUT_BF3) != 0;     // host guarantees: split mode, vec_ok, no PS2
   const int Cc = ps2 ? P.Cq : P.N;
   const size_t HfWf = (size_t)P.Hf * P.Wf;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    if (i > 0) __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        sC[srow * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
-      }
-    // one thread per slab row decodes the output position (the integer divisions happen once
-    // per row, not once per element): pixel index within the full output, and batch index
-    if (tid < SROWS) {
-      const int row = (tid >> 5) * (TM * 32) + i * 32 + (tid & 31);
-      const int p = m0 + row;
-      int pix = p, ob = 0;
-      if (!dense && p < P.P) {
-        ob = p / P.HoWo;
-        int rr = p - ob * P.HoWo;
-        int oy = rr / P.Wo;
-        int ox = rr - oy * P.Wo;
-        if (ps2) pix = (ob * P.Hf + 2 * oy) * P.Wf + 2 * ox;
-        else pix = (ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
-      }
-      sPix[2 * tid] = pix;
-      sPix[2 * tid + 1] = ob;
+  // output position of a tile row (the integer divisions happen once per row, not once per element): pixel index
+  // within the full output, and batch index
+  auto decode_row = [&](int row, int slot) {
+    const int p = m0 + row;
+    int pix = p, ob = 0;
+    if (!dense && p < P.P) {
+      ob = p / P.HoWo;
+      int rr = p - ob * P.HoWo;
+      int oy = rr / P.Wo;
+      int ox = rr - oy * P.Wo;
+      if (ps2) pix = (ob * P.Hf + 2 * oy) * P.Wf + 2 * ox;
+      else pix = (ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
     }
-    __syncthreads();
-    for (int it = tid; it < SROWS * (BN / 4); it += NT) {
-      const int srow = it / (BN / 4);
-      const int c4 = (it - srow * (BN / 4)) * 4;
-      const int row = (srow >> 5) * (TM * 32) + i * 32 + (srow & 31);   // slab row -> tile row
-      const int p = m0 + row;
-      const int n = n0 + c4;
-      if (p >= P.P || n >= P.N) continue;
-      const float4 av = *reinterpret_cast<const float4*>(sC + srow * LDC + c4);
-      float v[4] = {av.x, av.y, av.z, av.w};
-      const int pixb = sPix[2 * srow], ob = sPix[2 * srow + 1];
-      if (vec_ok) {
-        int cch = n;
+    sPix[2 * slot] = pix;
+    sPix[2 * slot + 1] = ob;
+  };
+  // four consecutive channels (c4..c4+3) of tile row `row`, held in LDS row `srow`
+  auto emit = [&](int srow, int row, int c4) {
+    const int p = m0 + row;
+    const int n = n0 + c4;
+    if (p >= P.P || n >= P.N) return;
+    const float4 av = *reinterpret_cast<const float4*>(sC + srow * LDC + c4);
+    float v[4] = {av.x, av.y, av.z, av.w};
+    const int pixb = sPix[2 * srow], ob = sPix[2 * srow + 1];
+    if (vec_ok) {
+      int cch = n;
+      size_t opix = (size_t)pixb;
+      if (ps2) {
+        int ph = n / P.Cq;
+        cch = n - ph * P.Cq;
+        opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
+      }
+      if (P.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (P.pre) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
+      if (P.mul) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
+        v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
+      }
+      if (P.post) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+      if (P.post2) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+      }
+      if (out_p3) {
+        // bf16x3 planes for the consuming convolution: [pixel][8-channel group][plane][8 bf16]; this lane owns
+        // channels cch..cch+3 = 8 bytes of each plane
+        unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hb[k] = __float_as_uint(v[k]);
+          const float r1 = v[k] - __uint_as_float(hb[k] & 0xFFFF0000u);
+          mb[k] = __float_as_uint(r1);
+          lb[k] = __float_as_uint(r1 - __uint_as_float(mb[k] & 0xFFFF0000u));
+        }
+        char* o3 = reinterpret_cast<char*>(P.out) + (opix * P.ldo + (size_t)(cch >> 3)) * 48 + (cch & 7) * 2;
+        *reinterpret_cast<uint2*>(o3) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+        *reinterpret_cast<uint2*>(o3 + 16) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+        *reinterpret_cast<uint2*>(o3 + 32) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+      } else {
+        *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
+      for (int k = 0; k < 4; ++k) {
+        const int nn = n + k;
+        if (nn >= P.N) break;
+        int cch = nn;
         size_t opix = (size_t)pixb;
         if (ps2) {
-          int ph = n / P.Cq;
-          cch = n - ph * P.Cq;
+          int ph = nn / P.Cq;
+          cch = nn - ph * P.Cq;
           opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
         }
-        if (P.bias) {
-          const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
-        if (P.pre) {
-          const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
-          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-        }
+        float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
+        if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
+        x = apply_act(x, P.act);
+        if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
+        if (P.post) x = x + P.post[opix * P.ld_post + cch];
+        if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
+        if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (opix - (size_t)ob * HfWf)] = x;
+        else P.out[opix * P.ldo + cch] = x;
+      }
+    }
+  };
+  if constexpr (SPEC) {
+    if ((int)threadIdx.x < BM) decode_row((int)threadIdx.x, (int)threadIdx.x);
+    __syncthreads();                         // the consumers' C tile and the row table are in LDS
+    for (int it = (int)threadIdx.x; it < BM * (BN / 4); it += NTB) {
+      const int row = it / (BN / 4);
+      emit(row, row, (it - row * (BN / 4)) * 4);
+    }
+  } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
-        if (P.mul) {
-          const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
-          v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
-        }
-        if (P.post) {
-          const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
-          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-        }
-        if (P.post2) {
-          const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
-          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
-        }
-        if (out_p3) {
-          // bf16x3 planes for the consuming convolution: [pixel][8-channel group][plane][8 bf16]; this lane owns
-          // channels cch..cch+3 = 8 bytes of each plane
-          unsigned hb[4], mb[4], lb[4];
+    for (int i = 0; i < TM; ++i) {
+      if (i > 0) __syncthreads();
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            hb[k] = __float_as_uint(v[k]);
-            const float r1 = v[k] - __uint_as_float(hb[k] & 0xFFFF0000u);
-            mb[k] = __float_as_uint(r1);
-            lb[k] = __float_as_uint(r1 - __uint_as_float(mb[k] & 0xFFFF0000u));
-          }
-          char* o3 = reinterpret_cast<char*>(P.out) + (opix * P.ldo + (size_t)(cch >> 3)) * 48 + (cch & 7) * 2;
-          *reinterpret_cast<uint2*>(o3) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
-          *reinterpret_cast<uint2*>(o3 + 16) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
-          *reinterpret_cast<uint2*>(o3 + 32) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
-        } else {
-          *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sC[srow * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
         }
-      } else {
-        // scalar path: model-edge NCHW store and phase groups that are not multiples of 4
-        for (int k = 0; k < 4; ++k) {
-          const int nn = n + k;
-          if (nn >= P.N) break;
-          int cch = nn;
-          size_t opix = (size_t)pixb;
-          if (ps2) {
-            int ph = nn / P.Cq;
-            cch = nn - ph * P.Cq;
-            opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
-          }
-          float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
-          if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
-          x = apply_act(x, P.act);
-          if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
-          if (P.post) x = x + P.post[opix * P.ld_post + cch];
-          if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
-          if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (opix - (size_t)ob * HfWf)] = x;
-          else P.out[opix * P.ldo + cch] = x;
-        }
+      if (tid < SROWS) decode_row((tid >> 5) * (TM * 32) + i * 32 + (tid & 31), tid);
+      __syncthreads();
+      for (int it = tid; it < SROWS * (BN / 4); it += NT) {
+        const int srow = it / (BN / 4);
+        emit(srow, (srow >> 5) * (TM * 32) + i * 32 + (srow & 31), (it - srow * (BN / 4)) * 4);
       }
     }
   }
@@ -844,15 +915,17 @@ static int conv_mode() {
   return g_mode;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0>
+template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
-  constexpr size_t pipe = MODE ? (size_t)((BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
+  constexpr size_t pipe = MODE ? (size_t)((SPEC || BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
                                : (size_t)2 * (BM + BN) * BK * sizeof(float);
-  constexpr size_t ctile = (size_t)WGM * 32 * (BN + 4) * sizeof(float) + (size_t)WGM * 32 * 2 * sizeof(int);
+  constexpr int crows = SPEC ? BM : WGM * 32;              // rows of C staged through LDS at a time
+  constexpr size_t ctile = (size_t)crows * (BN + 4) * sizeof(float) + (size_t)crows * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
+  static_assert(smem <= 160 * 1024, "tile does not fit the CU's LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN, SPEC>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
@@ -860,7 +933,7 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   int per_xcd = 0;
   for (int i = 0; i < ga.nprob; ++i) per_xcd += (ga.tile_start[i + 1] - ga.tile_start[i] + 7) / 8;
   (void)total_tiles;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN>), dim3(8 * per_xcd), dim3(WGM * WGN * 64), smem, s, ga);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, MODE, AIN, SPEC>), dim3(8 * per_xcd), dim3(WGM * WGN * 64 * (SPEC ? 2 : 1)), smem, s, ga);
   return check_launch("conv_igemm_kernel");
 }
 
@@ -1096,9 +1169,18 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
   if (conv_mode() == 1) {
+    static int spec = -1;                  // wave-specialised blocks (VAMPIC_SPEC=0 keeps the one-role kernel)
+    if (spec < 0) {
+      const char* e = getenv("VAMPIC_SPEC");
+      spec = (e && e[0] == '1') ? 1 : 0;
+    }
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
-    if (bm == BM_ && best_bn == BN_) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1>(ga, total, s) \
-                                                  : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 0>(ga, total, s);
+    if (bm == BM_ && best_bn == BN_) {                                                                      \
+      if (spec) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 1>(ga, total, s)                  \
+                             : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 0, 1>(ga, total, s);                 \
+      return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 0>(ga, total, s)                            \
+                   : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 0, 0>(ga, total, s);                           \
+    }
     VAM_CFG1(128, 32, 4, 1) VAM_CFG1(128, 64, 2, 2) VAM_CFG1(128, 96, 4, 1) VAM_CFG1(128, 128, 2, 2) VAM_CFG1(128, 192, 2, 2)
     VAM_CFG1(64, 32, 2, 1) VAM_CFG1(64, 64, 2, 2) VAM_CFG1(64, 128, 2, 2) VAM_CFG1(64, 192, 2, 2)
 #undef VAM_CFG1

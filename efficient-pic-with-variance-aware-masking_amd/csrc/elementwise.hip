@@ -219,6 +219,63 @@ __device__ __forceinline__ float eb_logits(const float* sp /*61 preprocessed flo
   return v + q[3];
 }
 
+// EntropyBottleneck.loss (entropy_models.py:398-401): sum_c,k |logits_cumulative(quantiles[c,k]) - target[k]| with the
+// network's own parameters held constant (stop_gradient), and its gradient w.r.t. the quantiles.  One thread per
+// (channel, quantile): the scalar 1-3-3-3-3-1 network is evaluated together with its derivative d logits / d x.
+__global__ void eb_aux_loss_kernel(const float* __restrict__ params, int C, float t0, float t1, float t2,
+                                   double* __restrict__ loss, float* __restrict__ dq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * C) return;
+  const int c = i / 3, k3 = i - 3 * c;
+  const float* m0 = params;
+  const float* b0 = m0 + C * 3;
+  const float* f0 = b0 + C * 3;
+  const float* base = f0 + C * 3;
+  const float* p = base;                                 // skip the three middle layers to reach the quantiles
+  for (int layer = 0; layer < 3; ++layer) p += C * 9 + C * 3 + C * 3;
+  const float* m4 = p;
+  const float* b4 = m4 + C * 3;
+  const float* qn = b4 + C;
+  const float x = qn[c * 3 + k3];
+  float l[3], dl[3];
+  for (int k = 0; k < 3; ++k) {
+    const float a = softplusf(m0[c * 3 + k]);
+    const float v = a * x + b0[c * 3 + k];
+    const float f = tanhf(f0[c * 3 + k]), th = tanhf(v);
+    l[k] = v + f * th;
+    dl[k] = a * (1.0f + f * (1.0f - th * th));
+  }
+  for (int layer = 0; layer < 3; ++layer) {
+    const float* m = base;
+    const float* b = m + C * 9;
+    const float* f = b + C * 3;
+    float t[3], dt[3];
+    for (int k = 0; k < 3; ++k) {
+      float v = b[c * 3 + k], dv = 0.f;
+      for (int j = 0; j < 3; ++j) {
+        const float w = softplusf(m[c * 9 + k * 3 + j]);
+        v += w * l[j];
+        dv += w * dl[j];
+      }
+      const float ff = tanhf(f[c * 3 + k]), th = tanhf(v);
+      t[k] = v + ff * th;
+      dt[k] = dv * (1.0f + ff * (1.0f - th * th));
+    }
+    for (int k = 0; k < 3; ++k) { l[k] = t[k]; dl[k] = dt[k]; }
+    base = f + C * 3;
+  }
+  float v = b4[c], dv = 0.f;
+  for (int j = 0; j < 3; ++j) {
+    const float w = softplusf(m4[c * 3 + j]);
+    v += w * l[j];
+    dv += w * dl[j];
+  }
+  const float tgt = k3 == 0 ? t0 : (k3 == 1 ? t1 : t2);
+  const float d = v - tgt;
+  atomicAdd(loss, (double)fabsf(d));
+  dq[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * dv;
+}
+
 __global__ void eb_forward_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ params, int C,
                                   float* __restrict__ zhat, int ld_zhat, float* __restrict__ lik, int ld_lik,
                                   int32_t* __restrict__ sym, int ld_sym, double* log2sum, int pix_per_item, long n_pix,
@@ -403,6 +460,15 @@ int vam_eb_forward_noise(const float* z, int ld_z, const float* params, int C, f
   hipLaunchKernelGGL(eb_forward_kernel, dim3(grid), dim3(block), smem, (hipStream_t)stream, z, ld_z, params, C, zhat,
                      ld_zhat, lik, ld_lik, sym, ld_sym, log2sum, pix_per_item, n_pix, noise, ld_noise);
   return check_launch("eb_forward_kernel");
+}
+
+int vam_eb_aux_loss(const float* params, int C, const float* target3_host, double* loss, float* dquantiles, void* stream) {
+  VAM_REQUIRE(params && target3_host && loss && dquantiles && C > 0, "vam_eb_aux_loss: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  VAM_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), s));
+  hipLaunchKernelGGL(eb_aux_loss_kernel, dim3(cdiv(3L * C, 64)), dim3(64), 0, s, params, C, target3_host[0], target3_host[1],
+                     target3_host[2], loss, dquantiles);
+  return check_launch("eb_aux_loss_kernel");
 }
 
 int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, long n_pix, int C,

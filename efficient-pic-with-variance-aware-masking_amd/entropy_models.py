@@ -16,11 +16,36 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import bitstream as bs
 from . import ops
 from .layers import _LowerBound, _no_autograd
 
 _NOT_BUILT = "training-mode paths (noise, autograd, aux loss) need the backward kernels (SURVEY K14); not built yet"
+
+
+class _EbAuxLoss(torch.autograd.Function):
+    """loss and d loss / d quantiles in one launch of vam_eb_aux_loss."""
+
+    @staticmethod
+    def forward(ctx, quantiles, eb):
+        import ctypes as C
+        L.require_gpu()
+        assert quantiles.is_cuda, "the entropy bottleneck's auxiliary loss runs on the GPU (no CPU fallback)"
+        pp = eb.packed_params()
+        loss = torch.zeros(1, dtype=torch.float64, device=quantiles.device)
+        dq = torch.empty(quantiles.numel(), dtype=torch.float32, device=quantiles.device)
+        tgt = (C.c_float * 3)(*[float(v) for v in eb.target.detach().cpu().tolist()])
+        L.check(L.load().vam_eb_aux_loss(pp.data_ptr(), eb.channels, tgt, loss.data_ptr(), dq.data_ptr(), ops.stream_ptr()),
+                "vam_eb_aux_loss")
+        ctx.save_for_backward(dq)
+        ctx.shape = quantiles.shape
+        return loss.to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dq,) = ctx.saved_tensors
+        return g * dq.view(ctx.shape), None
 
 
 class EntropyModel(nn.Module):
@@ -188,7 +213,10 @@ class EntropyBottleneck(EntropyModel):
         return zhat.torch_nchw(), lik.torch_nchw()
 
     def loss(self):
-        raise NotImplementedError(_NOT_BUILT)
+        """entropy_models.py:398-401: |logits_cumulative(quantiles) - target| summed, a function of the quantiles only
+        (the density network is held constant); differentiable w.r.t. ``self.quantiles`` (models/base.py:22-29
+        ``aux_loss`` + the aux optimiser of utility/functions.py:27-59)."""
+        return _EbAuxLoss.apply(self.quantiles, self)
 
     def _logits_cumulative_host(self, v):
         """entropy_models.py:403-422 on the host (table building only; the per-pixel likelihood is

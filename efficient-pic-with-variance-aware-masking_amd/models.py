@@ -295,10 +295,19 @@ class VarianceMaskingPIC(CompressionModel):
             h = (h * 1000003 + p._version * 31 + (p.data_ptr() >> 4)) & 0xFFFFFFFFFFFFFFF
         return h
 
-    def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, clone=True):
-        """models/pic.py:497-666 (eval).  Returns the reference's dict; tensors are NCHW-shaped."""
-        if training:
-            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+    def _trainable_outside_rem(self):
+        return [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("post_latent.")]
+
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std", training=False, clone=True, noise=None):
+        """models/pic.py:497-666.  Returns the reference's dict; tensors are NCHW-shaped.  ``training=True``: the
+        additive-uniform-noise likelihoods of the training forward (entropy_models.py:132-138; the latents themselves
+        are STE-rounded, so every other output equals the eval pass) — VALUES only: the transforms outside the REMs have
+        no backward kernels in this build, so asking for their gradients fails loudly instead of silently
+        returning none.  ``noise`` = {"y": NCHW, "z": NCHW} injects fixed draws."""
+        if training and torch.is_grad_enabled() and self._trainable_outside_rem():
+            raise NotImplementedError("training-mode forward outside the REMs needs the backward kernels of g_a / g_s / "
+                                      "hyperprior / slice stacks (SURVEY K14), not built yet: call under torch.no_grad() "
+                                      f"or freeze {self._trainable_outside_rem()[:2]}...")
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
             raise NotImplementedError()
@@ -310,21 +319,23 @@ class VarianceMaskingPIC(CompressionModel):
             pr = 10                                   # channel_mask.py:152-153: all ones unless pr == 0
         nb = _max_images_per_plan(x)
         if x.shape[0] > nb:                            # tensors of one plan are addressed with 32-bit byte offsets
-            return _cat_outputs([self.forward_single_quality(x[i:i + nb], quality, mask_pol, False, True)
+            sub = lambda i: None if noise is None else {k: v[i:i + nb] for k, v in noise.items()}
+            return _cat_outputs([self.forward_single_quality(x[i:i + nb], quality, mask_pol, training, True, sub(i))
                                  for i in range(0, x.shape[0], nb)])
-        plan = self._plan(x, base_only=(quality == 0))
-        return plan.execute(x, pr, None, self.use_graph, clone)
+        plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training))
+        return plan.execute(x.detach(), pr, None, self.use_graph, clone, noise=noise)
 
-    def forward(self, x, quality=None, mask_pol=None, training=True):
-        """models/pic.py:301-491.  Eval only in this build: one pass per requested quality."""
-        if training:
-            raise NotImplementedError("training-mode forward needs the backward kernels (SURVEY K14); not built yet")
+    def forward(self, x, quality=None, mask_pol=None, training=True, noise=None):
+        """models/pic.py:301-491: the base pass plus one progressive pass per requested quality (default [0, 10]),
+        stacked as the reference stacks them.  ``training=True`` evaluates the likelihoods with additive uniform noise
+        (values only, see :meth:`forward_single_quality`); the same noise tensors serve every quality, as one
+        ``uniform_`` draw per slice would in a single reference pass."""
         qs = self.define_quality(quality)
-        base = self.forward_single_quality(x, 0, mask_pol, False)
+        base = self.forward_single_quality(x, 0, mask_pol, training, noise=noise)
         x_hats, y_prog, y_hat_total = [base["x_hat"].unsqueeze(0)], [], [base["y_hat"]]
         out = None
         for q in qs[1:]:
-            out = self.forward_single_quality(x, q, mask_pol, False)
+            out = self.forward_single_quality(x, q, mask_pol, training, noise=noise)
             x_hats.append(out["x_hat"].unsqueeze(0))
             y_prog.append(out["likelihoods"]["y"].unsqueeze(0))
             y_hat_total.append(out["y_hat"])

@@ -212,6 +212,10 @@ int vam_eb_forward(const float* z, int ld_z, const float* params, int C,
 int vam_eb_forward_noise(const float* z, int ld_z, const float* params, int C, float* zhat, int ld_zhat,
                          float* lik, int ld_lik, int32_t* sym, int ld_sym, double* log2sum, int pix_per_item,
                          long n_pix, const float* noise, int ld_noise, void* stream);
+/* EntropyBottleneck.loss (entropy_models.py:398-401; models/base.py:22-29 aux_loss): loss[0] (device double) =
+ * sum_{c,k} |logits_cumulative(quantiles[c,k]) - target[k]| with the density network held constant (stop_gradient),
+ * dquantiles[c*3+k] = d loss / d quantiles[c,k].  params as for vam_eb_forward; target3_host: 3 HOST floats. */
+int vam_eb_aux_loss(const float* params, int C, const float* target3_host, double* loss, float* dquantiles, void* stream);
 /* EntropyModel.dequantize (entropy_models.py:161-168): out = float(sym) + mu (mu may be NULL). */
 int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, float* out, int ld_out,
                    long n_pix, int C, void* stream);

@@ -108,9 +108,12 @@ def main():
     fill(eb, 40)
     z = g((2, 192, 4, 6), 41, 5.0)
     zh, zl = eb(z, training=False)
+    aux = eb.loss()                                    # entropy_models.py:398-401 (aux_loss of models/base.py:22-29)
+    aux.backward()
     np.savez_compressed(os.path.join(GOLD, "entropy_ops.npz"), gc_out=out.numpy(), gc_lik=lik.numpy(),
                         gc_out_nomean=out2.numpy(), gc_lik_nomean=lik2.numpy(), gc_idx=idx.numpy().astype(np.int8),
-                        eb_zhat=zh.detach().numpy(), eb_lik=zl.detach().numpy())
+                        eb_zhat=zh.detach().numpy(), eb_lik=zl.detach().numpy(),
+                        eb_aux_loss=np.array([aux.item()], dtype=np.float64), eb_aux_dq=eb.quantiles.grad.numpy())
 
     # 4. layer-level vectors
     rec = {}

@@ -550,6 +550,15 @@ def gaussian_likelihood_noise(inputs: Tensor, scales: Tensor, means: Optional[Te
     return lower_bound(lik, LIKELIHOOD_BOUND)
 
 
+def eb_aux_loss(sd: SD, prefix: str = "entropy_bottleneck.") -> Tensor:
+    """``EntropyBottleneck.loss`` (entropy_models.py:398-401): the density network's parameters are constants
+    (stop_gradient=True), only ``quantiles`` carries a gradient."""
+    const = {k: (v if k.endswith("quantiles") else v.detach()) for k, v in sd.items() if k.startswith(prefix)}
+    logits = eb_logits_cumulative(const, sd[prefix + "quantiles"], prefix)
+    target = math.log(2 / 1e-9 - 1)
+    return torch.abs(logits - torch.tensor([-target, 0.0, target])).sum()
+
+
 def eb_likelihood_noise(sd: SD, z: Tensor, noise: Tensor, prefix: str = "entropy_bottleneck.") -> Tensor:
     """Training-mode ``EntropyBottleneck.forward`` likelihood: evaluated at z + noise (entropy_models.py:471-478)."""
     B, C = z.shape[:2]

@@ -129,8 +129,9 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         if q > 0:
             m = cpu["mask"].numpy().astype(np.uint8)
             assert np.array_equal(np.packbits(m.reshape(-1)), gold[tag + "_mask"]), tag     # reference's mask bits
-        if 0 < q < 10:
-            assert np.array_equal(gold[tag + "_thr"], _thresholds(net, 1, 256, 256)), tag   # reference's thresholds
+        if 0 < q < 10:       # thresholds follow sigma (a conv output: fp32 summation order), the BITS they select are identical
+            thr = _thresholds(net, 1, 256, 256)
+            assert np.abs(thr - gold[tag + "_thr"]).max() <= 2e-5 * np.abs(gold[tag + "_thr"]).max(), tag
         assert np.abs(ys - gold[tag + "_y_hat"]).max() <= 2e-4 * max(1.0, np.abs(gold[tag + "_y_hat"]).max()), tag
         assert np.abs(xs - gold[tag + "_x_hat"]).max() <= 1e-4, tag
         mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()

@@ -289,18 +289,31 @@ def test_rem_finetune_step_full_size_teacher_forced(train_model):
     N = 32
     nchw = lambda v: v.torch_nchw().detach().cpu().clone()
     for j in (0, 4, 9):
-        leaves = {"r." + n: t.detach().cpu().clone().requires_grad_(True) for n, t in m.post_latent[0][j].state_dict().items()}
+        # reference gradient in float64 (autograd over the oracle's rem_block): each weight gradient is a sum over
+        # 16 x 256 = 4096 positions, so two fp32 evaluations of it (ATen's and the wgrad kernel's, different summation
+        # orders) differ by ~sqrt(4096) * eps * (cancellation) of each other; both are held against the float64 value
         a = nchw(att[j])
-        res = O.rem_block(leaves, "r.", nchw(ck[j]), torch.cat([nchw(epb[j][0]), nchw(epb[j][1])], 1),
-                          torch.cat([nchw(epp[j][0]), nchw(epp[j][1])], 1), torch.cat([a, a], 1))
+        ins = (nchw(ck[j]), torch.cat([nchw(epb[j][0]), nchw(epb[j][1])], 1),
+               torch.cat([nchw(epp[j][0]), nchw(epp[j][1])], 1), torch.cat([a, a], 1))
         dres = torch.cat([nchw(plan.dmu.window(j * N, N)), nchw(plan.dsg.window(j * N, N))], 1)
-        res.backward(dres)
+        grads = {}
+        for dt in (torch.float32, torch.float64):
+            leaves = {"r." + n: t.detach().cpu().to(dt).clone().requires_grad_(True)
+                      for n, t in m.post_latent[0][j].state_dict().items()}
+            res = O.rem_block(leaves, "r.", *[t.to(dt) for t in ins])
+            res.backward(dres.to(dt))
+            grads[dt] = (res.detach(), {k: v.grad for k, v in leaves.items()})
         # forward agreement of the refined parameters on the same inputs
         got = torch.cat([nchw(plan.mu_f.window(j * N, N)), nchw(plan.std_f.window(j * N, N))], 1)
-        assert _rel(got, res) <= 1e-5, j
+        assert _rel(got, grads[torch.float64][0]) <= 1e-5, j
+        worst_gpu = worst_cpu = 0.0
         for n, p in m.post_latent[0][j].named_parameters():
             assert p.grad is not None, (j, n)
-            assert _rel(p.grad, leaves["r." + n].grad) <= 2e-5, (j, n, _rel(p.grad, leaves["r." + n].grad))
+            g64 = grads[torch.float64][1]["r." + n]
+            e_gpu, e_cpu = _rel(p.grad, g64), _rel(grads[torch.float32][1]["r." + n], g64)
+            worst_gpu, worst_cpu = max(worst_gpu, e_gpu), max(worst_cpu, e_cpu)
+            assert e_gpu <= max(1.5e-4, 4 * e_cpu), (j, n, e_gpu, e_cpu)
+        print(f"slice {j}: worst gradient error vs float64: HIP {worst_gpu:.2e}, ATen fp32 {worst_cpu:.2e}")
     # the other REMs (other check levels) and everything frozen stay without gradients
     assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("post_latent.0."))
     # likelihood backward at full size against the oracle's autograd on the plan's own (y, mu', sigma', mask, noise)
