@@ -287,3 +287,29 @@ def test_bf16x3_plane_tensors_are_transparent():
     assert torch.equal(q3.buf, q32.buf)
     with pytest.raises(Exception):                                                      # formats do not mix within a problem
         ops.conv_problem(m2.packed(), [mid3.window(0, 88), mid32.window(88, 88)], o3)
+
+
+def test_entropy_bottleneck_aux_loss_and_gradient():
+    """model.aux_loss() (models/base.py:22-29 -> EntropyBottleneck.loss, entropy_models.py:398-401): value and the
+    gradient w.r.t. the quantiles from vam_eb_aux_loss against the REFERENCE's autograd (tests/golden/entropy_ops.npz),
+    and one step of the aux optimiser moves the quantiles (utility/functions.py:27-59)."""
+    import os
+    from vampic.entropy_models import EntropyBottleneck
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "entropy_ops.npz"))
+    eb = EntropyBottleneck(192)
+    eb.load_state_dict(synth.synth_state_dict(eb.state_dict(), 40))
+    eb = eb.cuda()
+    loss = eb.loss()
+    loss.backward()
+    assert abs(float(loss) - gold["eb_aux_loss"][0]) <= 2e-5 * abs(gold["eb_aux_loss"][0]), (float(loss), gold["eb_aux_loss"][0])
+    g = eb.quantiles.grad.cpu().numpy()
+    assert np.abs(g - gold["eb_aux_dq"]).max() <= 2e-5 * np.abs(gold["eb_aux_dq"]).max()
+    assert all(p.grad is None for n, p in eb.named_parameters() if n != "quantiles")       # stop_gradient on the network
+    opt = torch.optim.Adam([eb.quantiles], lr=1e-2)
+    before = float(loss)
+    for _ in range(20):
+        opt.zero_grad()
+        l = eb.loss()
+        l.backward()
+        opt.step()
+    assert float(eb.loss()) < before

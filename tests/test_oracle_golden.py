@@ -225,3 +225,18 @@ def test_oracle_reproduces_reference_config_variants():
             _close(o["x_hat"][:, :, ::2, ::2], gold[tag + "_x_hat"], 2e-5)
             assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4, tag
             assert abs(O.bpp(o["likelihoods"], 4096) - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), tag
+
+
+def test_oracle_aux_loss_matches_reference():
+    """EntropyBottleneck.loss and its gradient w.r.t. the quantiles (entropy_models.py:398-401) against the reference's
+    own autograd (tests/golden/entropy_ops.npz: eb_aux_loss, eb_aux_dq)."""
+    import vampic
+    from vampic.entropy_models import EntropyBottleneck
+    gold = np.load(os.path.join(GOLD, "entropy_ops.npz"))
+    eb = EntropyBottleneck(192)
+    sd = {"entropy_bottleneck." + k: v.clone() for k, v in synth.synth_state_dict(eb.state_dict(), 40).items()}
+    sd["entropy_bottleneck.quantiles"].requires_grad_(True)
+    loss = O.eb_aux_loss(sd)
+    loss.backward()
+    assert abs(loss.item() - gold["eb_aux_loss"][0]) <= 1e-5 * abs(gold["eb_aux_loss"][0])
+    _close(sd["entropy_bottleneck.quantiles"].grad, gold["eb_aux_dq"], 1e-5)
