@@ -19,7 +19,10 @@ ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQR
 # enum vam_conv_flags
 CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW, CONV_IN_BF3, CONV_OUT_BF3 = 1, 2, 4, 8, 16
 # enum vam_pack_mode
-PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD = range(5)
+PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD, PACK_GDN_T = range(6)
+# enum vam_ew_op
+(EW_GELU_FWD, EW_GELU_BWD, EW_GATE_BWD, EW_GDN_APPLY, EW_GDN_BWD_PREP, EW_GDN_BWD_FIN, EW_CLAMP_BWD, EW_AXPY, EW_GATE_FWD,
+ EW_REPARAM_BWD) = range(10)
 # enum vam_family
 FAM_CONV, FAM_ATTN, FAM_MASK, FAM_TAIL, FAM_MISC = range(5)
 FAMILY_NAMES = ("conv_igemm", "win_attn", "variance_mask", "gauss_tail", "misc")
@@ -38,11 +41,16 @@ class VamWgrad(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
                 ("ld_x", C.c_int), ("ld_dy", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("C", C.c_int), ("N", C.c_int),
-                ("cin_total", C.c_int), ("c_off", C.c_int)]
+                ("cin_total", C.c_int), ("c_off", C.c_int), ("stride", C.c_int), ("Hx", C.c_int), ("Wx", C.c_int)]
 
 
 class VamAux(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("pad_", C.c_int32)]
+
+
+class VamEw(C.Structure):
+    _fields_ = [("inp", VamAux * 4), ("out", VamAux * 3), ("n_pix", C.c_long), ("C", C.c_int32), ("flag", C.c_int32),
+                ("coef", C.c_float), ("pad_", C.c_int32)]
 
 
 class VamConv(C.Structure):
@@ -105,6 +113,9 @@ _SIGNATURES = {
     "vam_leaky_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_gauss_train": (C.c_int, [C.c_void_p, C.c_int] * 10 + [C.c_long, C.c_int, C.c_void_p]),
+    "vam_train_elementwise": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                              + [C.c_int] * 7 + [C.c_void_p]),
     "vam_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_rans_encode": (C.c_long, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "vam_rans_decode": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

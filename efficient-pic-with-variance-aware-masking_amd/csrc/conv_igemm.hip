@@ -596,6 +596,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // (the consumers' operand reads and MFMAs are left to hipcc's scheduler: a hand-pipelined variant that issued
+        // the next sub-step's fragment reads ahead of each MFMA block and pinned the order with sched_barrier(0) measured
+        // 10-25 % SLOWER on every tile — the pinned order keeps the compiler from interleaving reads and MFMAs)
         __syncthreads();
         for (int ch = 0; ch < n_chunks; ch += 2) {
           compute(0);
@@ -807,8 +810,8 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ src, int m
       // data gradient of a stride-1 conv = correlation of dY with the taps flipped and the channel roles
       // swapped: here `cin` = forward Cout (channels of dY), `n` = forward Cin; src is the forward OIHW tensor
       v = src[(((size_t)cc * n + nn) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
-    } else if (mode == VAM_PACK_GDN) {
-      float g = src[(size_t)nn * cin + cc];
+    } else if (mode == VAM_PACK_GDN || mode == VAM_PACK_GDN_T) {
+      float g = mode == VAM_PACK_GDN ? src[(size_t)nn * cin + cc] : src[(size_t)cc * n + nn];   // _T: gamma transposed
       const float bound = 3.814697265625e-06f;       // 2^-18 = sqrt(0 + 2^-36)
       const float ped = 1.4551915228366852e-11f;     // 2^-36
       g = fmaxf(g, bound);
@@ -977,12 +980,12 @@ size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
 int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int kh, int kw, int cin, int n,
                           void* stream) {
   VAM_REQUIRE(src && dst && kh > 0 && kw > 0 && cin > 0 && n > 0, "vam_pack_conv_weights: bad arguments");
-  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_CONV_DGRAD, "vam_pack_conv_weights: bad mode %d", mode);
+  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_GDN_T, "vam_pack_conv_weights: bad mode %d", mode);
   if (mode == VAM_PACK_PS2) VAM_REQUIRE(n % 4 == 0, "PS2 pack needs N %% 4 == 0");
   if (mode == VAM_PACK_DECONV5S2 && phase < 0) VAM_REQUIRE(n % 4 == 0 && kh == 3 && kw == 3, "merged deconv pack needs 3x3, N=4*Cout");
   if (mode == VAM_PACK_DECONV5S2 && phase >= 0)
     VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
-  if (mode == VAM_PACK_GDN) VAM_REQUIRE(kh == 1 && kw == 1, "GDN pack is 1x1");
+  if (mode == VAM_PACK_GDN || mode == VAM_PACK_GDN_T) VAM_REQUIRE(kh == 1 && kw == 1 && cin == n, "GDN pack is 1x1 and square");
   int npad = (n + 31) / 32 * 32;
   if (conv_mode() == 1) {
     const int kc32 = (cin + 31) / 32;
@@ -1169,11 +1172,22 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
   if (conv_mode() == 1) {
-    static int spec = -1;                  // wave-specialised blocks (VAMPIC_SPEC=0 keeps the one-role kernel)
-    if (spec < 0) {
+    // Wave-specialised blocks where they measured faster (interleaved A/B on one box, scratch/ab_spec.sh): the small
+    // tiles of the slice chain (64x32 / 64x64 / 64x128: +12...+32 %) and the large tiles of deep-K layers (128x128,
+    // 128x192: +3...+7 %); short-K layers (1x1, the 16-channel first layer) and the 4x1-wave 128x96 tile lose 15-30 %
+    // (a longer prologue, one block per CU) and keep the one-role kernel.  VAMPIC_SPEC=0 / 1 forces one kind everywhere.
+    static int spec_env = -2;
+    if (spec_env == -2) {
       const char* e = getenv("VAMPIC_SPEC");
-      spec = (e && e[0] == '1') ? 1 : 0;
+      spec_env = e ? (e[0] == '1' ? 1 : 0) : -1;
     }
+    int min_chunks = 1 << 30;
+    for (int i = 0; i < nprob; ++i) {
+      const int nc = ga.p[i].kh * ga.p[i].kw * ga.p[i].Kc;
+      if (nc < min_chunks) min_chunks = nc;
+    }
+    const bool spec_tile = (bm == 64 && (best_bn == 32 || best_bn == 64 || best_bn == 128)) || (bm == 128 && (best_bn == 128 || best_bn == 192));
+    const bool spec = spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16);
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
     if (bm == BM_ && best_bn == BN_) {                                                                      \
       if (spec) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 1>(ga, total, s)                  \

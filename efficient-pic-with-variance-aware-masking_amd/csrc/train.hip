@@ -41,6 +41,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int H = pr.H, W = pr.W, HW = H * W;
+  const int stride = pr.stride == 2 ? 2 : 1;                       // 2: the k5/s2/p2 convolution (x is [B, Hx, Wx])
+  const int Hx = stride == 2 ? pr.Hx : H, Wx = stride == 2 ? pr.Wx : W;
+  const long HWx = (long)Hx * Wx;
   const long P = (long)pr.B * HW;
   const float* __restrict__ x = pr.x;
   const float* __restrict__ dy = pr.dy;
@@ -63,9 +66,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
         const int bi = (int)(p / HW);
         const int r = (int)(p - (long)bi * HW);
         const int oy = r / W, ox = r - oy * W;
-        const int iy = oy - pad_y + ty, ix = ox - pad_x + tx;
-        if (c_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-          b[i] = x[((long)bi * HW + (long)iy * W + ix) * ld_x + c0 + l31];
+        const int iy = oy * stride - pad_y + ty, ix = ox * stride - pad_x + tx;
+        if (c_ok && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx)
+          b[i] = x[((long)bi * HWx + (long)iy * Wx + ix) * ld_x + c0 + l31];
       }
     }
 #pragma unroll
@@ -222,7 +225,9 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   for (int i = 0; i < n_probs; ++i) {
     const vam_wgrad& p = probs[i];
     VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
-    VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (stride 1, pad k/2)");
+    VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (pad k/2)");
+    VAM_REQUIRE(p.stride == 0 || p.stride == 1 || (p.stride == 2 && p.kh == 5 && p.Hx == 2 * p.H && p.Wx == 2 * p.W),
+                "vam_conv_wgrad_group: problem %d: stride %d (1, or 2 with k5 and x of extent 2H x 2W)", i, p.stride);
     VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
     int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
     max_blocks = nb > max_blocks ? nb : max_blocks;
@@ -241,6 +246,7 @@ int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, 
   p.x = x; p.dy = dy; p.dw = dw; p.db = db;
   p.ld_x = ld_x; p.ld_dy = ld_dy; p.B = B; p.H = H; p.W = W; p.kh = kh; p.kw = kw; p.C = C; p.N = N;
   p.cin_total = cin_total; p.c_off = c_off;
+  p.stride = 1; p.Hx = H; p.Wx = W;
   return vam_conv_wgrad_group(&p, 1, stream);
 }
 

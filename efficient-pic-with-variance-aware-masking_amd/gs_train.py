@@ -1,0 +1,316 @@
+"""Training-mode lowering of a synthesis transform (first schedule: ``--training_type refine_gs``,
+reference train.py:150-157,216-218 — everything frozen except ``g_s[1]``; loss = DistortionLoss, training/loss.py:126-187).
+
+Forward: the same kernels as the eval lowering (engine.lower_g_s), but every tensor the backward needs is kept ("tape"):
+pre-activations of the GELUs, the pre-sigmoid gate operand, the IGDN norm pool, qkv.  Activations that the eval path
+applies in the producing convolution's epilogue are applied by an element-wise kernel with the SAME formula here, so the
+forward values are bit-identical to the eval path.
+
+Backward (its own plan): clamp -> transposed-conv data / weight gradients -> IGDN -> attention block -> ..., in reverse.
+  * data gradient of a stride-1 conv / Linear: the conv kernel on VAM_PACK_CONV_DGRAD weights;
+  * data gradient of ConvTranspose2d(k5, s2, p2, op1): a k5/s2/p2 convolution with the SAME weight tensor read as OIHW;
+  * its weight gradient: vam_conv_wgrad (stride 2) with the roles of input and output gradient exchanged;
+  * IGDN:  y = x * sqrt(n), n = beta' + gamma' x^2:  dn = dy x / (2 sqrt n);  dx = dy sqrt n + 2 x (gamma'^T dn);
+           dgamma' = dn (x^2)^T, dbeta' = sum dn, then the NonNegativeParametrizer chain (LowerBound rule);
+  * window attention: csrc/train_gs.hip (softmax backward, dq/dk/dv, relative-position-bias gradient).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import layers as Ly
+from . import ops
+from .ops import View
+
+_GAMMA_BOUND = 2.0 ** -18                        # NonNegativeParametrizer(): sqrt(0 + 2^-36)
+_BETA_BOUND = (1e-6 + 2.0 ** -36) ** 0.5         # NonNegativeParametrizer(minimum=1e-6)
+
+
+class TransformPacks:
+    """Forward and data-gradient packed weights of every layer of ONE transform stack, re-packed IN PLACE at the head of
+    every step (the optimiser changes the parameters between steps; plans and graphs keep their pointers)."""
+
+    def __init__(self, stack: nn.Module):
+        self.f: Dict[int, object] = {}
+        self.d: Dict[int, ops.Packed] = {}
+        self._refresh = []
+        self.keep = []
+        for m in stack.modules():
+            if isinstance(m, Ly.Conv2d):
+                assert m.stride == 1 and not m.is_rgb_s2d, "training lowering: stride-1 convolutions (synthesis transform)"
+                self._add_conv(m)
+            elif isinstance(m, Ly.Linear):
+                self._add_linear(m)
+            elif isinstance(m, Ly.ConvTranspose2d):
+                self._add_deconv(m)
+            elif isinstance(m, Ly.GDN):
+                self._add_gdn(m)
+
+    def _add_conv(self, c):
+        n, cin, k = c.out_channels, c.in_channels, c.kernel_size
+        f = ops.pack_conv(c.weight, c.bias, 1)
+        d = ops.pack_conv_dgrad(c.weight)
+        self.f[id(c)], self.d[id(c)] = f, d
+
+        def refresh():
+            ops.repack_weights(c.weight, f.w, L.PACK_CONV, 0, k, k, cin, n)
+            ops.repack_bias(c.bias, f.b, L.PACK_CONV, n)
+            ops.repack_weights(c.weight, d.w, L.PACK_CONV_DGRAD, 0, k, k, n, cin)
+        self._refresh.append(refresh)
+
+    def _add_linear(self, l):
+        n, cin = l.out_features, l.in_features
+        f = ops.pack_linear(l.weight, l.bias)
+        d = ops.Packed(ops.pack_weights(l.weight.detach().reshape(n, cin, 1, 1), L.PACK_CONV_DGRAD, 0, 1, 1, n, cin), None,
+                       1, 1, n, cin)
+        self.f[id(l)], self.d[id(l)] = f, d
+
+        def refresh():
+            ops.repack_weights(l.weight, f.w, L.PACK_CONV, 0, 1, 1, cin, n)
+            ops.repack_bias(l.bias, f.b, L.PACK_CONV, n)
+            ops.repack_weights(l.weight, d.w, L.PACK_CONV_DGRAD, 0, 1, 1, n, cin)
+        self._refresh.append(refresh)
+
+    def _add_deconv(self, m):
+        ci, co = m.in_channels, m.out_channels
+        f = ops.pack_deconv(m.weight, m.bias)
+        # data gradient: dx[ci] = conv5x5 s2 p2 over dy[co] with W[ci][co][ky][kx] read as OIHW (O = ci, I = co); the
+        # conv kernel wants input channels in multiples of 16, so a 3-channel output gradient is zero-padded
+        cp = (co + 15) // 16 * 16
+        wsrc = m.weight if cp == co else torch.zeros((ci, cp, 5, 5), dtype=torch.float32, device=m.weight.device)
+        if cp != co:
+            wsrc[:, :co].copy_(m.weight.detach())
+            self.keep.append(wsrc)
+        d = ops.Packed(ops.pack_weights(wsrc, L.PACK_CONV, 0, 5, 5, cp, ci), None, 5, 5, cp, ci, 2, 2, 2)
+        self.f[id(m)], self.d[id(m)] = f, d
+
+        def refresh():
+            if len(f) == 4:
+                for ph, pk in enumerate(f):
+                    ops.repack_weights(m.weight, pk.w, L.PACK_DECONV5S2, ph, pk.kh, pk.kw, ci, co)
+                ops.repack_bias(m.bias, f[0].b, L.PACK_CONV, co)
+            else:
+                ops.repack_weights(m.weight, f[0].w, L.PACK_DECONV5S2, -1, 3, 3, ci, 4 * co)
+                ops.repack_bias(m.bias, f[0].b, L.PACK_DECONV5S2, 4 * co)
+            if cp != co:
+                wsrc[:, :co].copy_(m.weight.detach())
+            ops.repack_weights(wsrc, d.w, L.PACK_CONV, 0, 5, 5, cp, ci)
+        self._refresh.append(refresh)
+
+    def _add_gdn(self, g):
+        c = g.in_channels
+        f = ops.pack_gdn(g.beta, g.gamma)
+        d = ops.Packed(ops.pack_weights(g.gamma, L.PACK_GDN_T, 0, 1, 1, c, c), None, 1, 1, c, c)
+        self.f[id(g)], self.d[id(g)] = f, d
+
+        def refresh():
+            ops.repack_weights(g.gamma, f.w, L.PACK_GDN, 0, 1, 1, c, c)
+            ops.repack_bias(g.beta, f.b, L.PACK_GDN, c)
+            ops.repack_weights(g.gamma, d.w, L.PACK_GDN_T, 0, 1, 1, c, c)
+        self._refresh.append(refresh)
+
+    def record_refresh(self, plan: E.Plan):
+        fns = list(self._refresh)
+        plan.call(lambda: [fn() for fn in fns], f"repack {len(fns)} trained layers")
+
+
+# ============================================================================= forward (taped)
+def _gelu(plan, pre: View) -> View:
+    o = plan.buf(pre.B, pre.H, pre.W, pre.C)
+    plan.call(lambda: ops.ew(L.EW_GELU_FWD, [pre], [o]), "gelu")
+    return o
+
+
+def _ru_fwd(plan, pk: TransformPacks, ru: Ly.ResidualUnit, x: View, tape: list) -> View:
+    """GELU(conv1x1(GELU(conv3x3(GELU(conv1x1(x))))) + x)   (layers/layers.py:30-48)."""
+    c1, c2, c3 = ru.conv[0], ru.conv[2], ru.conv[4]
+    h1p = plan.buf(x.B, x.H, x.W, c1.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c1)], [x], h1p)])
+    h1 = _gelu(plan, h1p)
+    h2p = plan.buf(x.B, x.H, x.W, c2.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c2)], [h1], h2p)])
+    h2 = _gelu(plan, h2p)
+    op = plan.buf(x.B, x.H, x.W, c3.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c3)], [h2], op, pre=x)])
+    o = _gelu(plan, op)
+    tape.append(dict(kind="ru", mod=ru, x=x, h1p=h1p, h1=h1, h2p=h2p, h2=h2, op=op))
+    return o
+
+
+def _attention_block_fwd(plan, pk, blk: Ly.Win_noShift_Attention, x: View, tape: list) -> View:
+    """a * sigmoid(b) + x  (layers/layers.py:50-74)."""
+    rec = dict(kind="attn", mod=blk, x=x, a_tape=[], b_tape=[])
+    wa = blk.conv_b[0]
+    qkv = plan.buf(x.B, x.H, x.W, 3 * x.C)
+    plan.conv([ops.conv_problem(pk.f[id(wa.attn.qkv)], [x], qkv)])
+    att = plan.buf(x.B, x.H, x.W, x.C)
+    tab = wa.attn.relative_position_bias_table
+    plan.call(lambda: ops.win_attention(qkv, att, tab, x.C, wa.num_heads, wa.window_size, wa.shift_size), "win_attention")
+    b = plan.buf(x.B, x.H, x.W, x.C)
+    plan.conv([ops.conv_problem(pk.f[id(wa.attn.proj)], [att], b, post=x)])
+    rec.update(qkv=qkv, att=att)
+    for i in (1, 2, 3):
+        b = _ru_fwd(plan, pk, blk.conv_b[i], b, rec["b_tape"])
+    b4p = plan.buf(x.B, x.H, x.W, x.C)
+    plan.conv([ops.conv_problem(pk.f[id(blk.conv_b[4])], [b], b4p)])
+    a = x
+    for i in range(3):
+        a = _ru_fwd(plan, pk, blk.conv_a[i], a, rec["a_tape"])
+    out = plan.buf(x.B, x.H, x.W, x.C)
+    plan.call(lambda: ops.ew(L.EW_GATE_FWD, [a, b4p, x], [out]), "gate")
+    rec.update(a=a, b3=b, b4p=b4p)
+    tape.append(rec)
+    return out
+
+
+def _deconv_fwd(plan, pk, m: Ly.ConvTranspose2d, x: View, tape: list, out_nchw: Optional[torch.Tensor] = None,
+                act: int = L.ACT_NONE) -> Optional[View]:
+    o = None if out_nchw is not None else plan.buf(x.B, 2 * x.H, 2 * x.W, m.out_channels)
+    plan.conv([ops.conv_problem(p, [x], o, act, out_nchw=out_nchw) for p in pk.f[id(m)]])
+    tape.append(dict(kind="deconv", mod=m, x=x))
+    return o
+
+
+def _gdn_fwd(plan, pk, g: Ly.GDN, x: View, tape: list) -> View:
+    n = plan.buf(x.B, x.H, x.W, x.C)
+    plan.conv([ops.conv_problem(pk.f[id(g)], [x], n, L.ACT_NONE, flags=L.CONV_SQUARE_IN)])
+    y = plan.buf(x.B, x.H, x.W, x.C)
+    plan.call(lambda: ops.ew(L.EW_GDN_APPLY, [x, n], [y], flag=1 if g.inverse else 0), "gdn apply")
+    tape.append(dict(kind="gdn", mod=g, x=x, n=n))
+    return y
+
+
+def lower_g_s_train(plan: E.Plan, dec: nn.Sequential, y: View, x_hat: torch.Tensor, pk: TransformPacks) -> list:
+    """models/builder.py:8-18 + clamp_(0, 1) (pic.py:651), keeping the tape.  Values equal engine.lower_g_s."""
+    tape: list = []
+    t = _attention_block_fwd(plan, pk, dec[0], y, tape)
+    t = _deconv_fwd(plan, pk, dec[1], t, tape)
+    t = _gdn_fwd(plan, pk, dec[2], t, tape)
+    t = _deconv_fwd(plan, pk, dec[3], t, tape)
+    t = _gdn_fwd(plan, pk, dec[4], t, tape)
+    t = _attention_block_fwd(plan, pk, dec[5], t, tape)
+    t = _deconv_fwd(plan, pk, dec[6], t, tape)
+    t = _gdn_fwd(plan, pk, dec[7], t, tape)
+    _deconv_fwd(plan, pk, dec[8], t, tape, out_nchw=x_hat, act=L.ACT_CLAMP01)
+    return tape
+
+
+# ============================================================================= backward
+def _conv_bwd(bw, pk, layer, x: View, dy: View, grads, need_dx: bool = True, dx_post: Optional[View] = None) -> Optional[View]:
+    bw.wgrad(ops.wgrad_problems([x], dy, grads[id(layer.weight)], grads[id(layer.bias)]))
+    if not need_dx:
+        return None
+    dx = bw.buf(x.B, x.H, x.W, x.C)
+    bw.conv([ops.conv_problem(pk.d[id(layer)], [dy], dx, post=dx_post)])
+    return dx
+
+
+def _gelu_bwd(bw, pre: View, dy: View) -> View:
+    o = bw.buf(pre.B, pre.H, pre.W, pre.C)
+    bw.call(lambda: ops.ew(L.EW_GELU_BWD, [pre, dy], [o]), "gelu bwd")
+    return o
+
+
+def _ru_bwd(bw, pk, r: dict, d_o: View, grads, need_dx: bool = True) -> Optional[View]:
+    ru = r["mod"]
+    c1, c2, c3 = ru.conv[0], ru.conv[2], ru.conv[4]
+    dop = _gelu_bwd(bw, r["op"], d_o)
+    d_h2 = _conv_bwd(bw, pk, c3, r["h2"], dop, grads)
+    dh2p = _gelu_bwd(bw, r["h2p"], d_h2)
+    d_h1 = _conv_bwd(bw, pk, c2, r["h1"], dh2p, grads)
+    dh1p = _gelu_bwd(bw, r["h1p"], d_h1)
+    return _conv_bwd(bw, pk, c1, r["x"], dh1p, grads, need_dx, dx_post=dop)          # + the residual path
+
+
+def _attention_block_bwd(bw, pk, r: dict, dout: View, grads, need_dx: bool) -> Optional[View]:
+    blk = r["mod"]
+    x = r["x"]
+    da, db4 = bw.buf(x.B, x.H, x.W, x.C), bw.buf(x.B, x.H, x.W, x.C)
+    bw.call(lambda: ops.ew(L.EW_GATE_BWD, [r["a"], r["b4p"], dout], [da, db4]), "gate bwd")
+    d = _conv_bwd(bw, pk, blk.conv_b[4], r["b3"], db4, grads)
+    for rr in reversed(r["b_tape"]):
+        d = _ru_bwd(bw, pk, rr, d, grads)
+    wa = blk.conv_b[0]
+    d_att = _conv_bwd(bw, pk, wa.attn.proj, r["att"], d, grads)
+    dqkv = bw.buf(x.B, x.H, x.W, 3 * x.C)
+    tab = wa.attn.relative_position_bias_table
+    dtab = grads[id(tab)]
+    bw.call(lambda: (ops.memset_zero(dtab), ops.win_attention_bwd(r["qkv"], d_att, dqkv, tab, dtab, x.C, wa.num_heads,
+                                                                 wa.window_size, wa.shift_size)), "win_attention bwd")
+    dx_b = _conv_bwd(bw, pk, wa.attn.qkv, x, dqkv, grads, need_dx, dx_post=d)          # + the shortcut of the Swin block
+    d = da
+    for i, rr in enumerate(reversed(r["a_tape"])):
+        d = _ru_bwd(bw, pk, rr, d, grads, need_dx or i < len(r["a_tape"]) - 1)
+    if not need_dx:
+        return None
+    t, dx = bw.buf(x.B, x.H, x.W, x.C), bw.buf(x.B, x.H, x.W, x.C)
+    bw.call(lambda: (ops.ew(L.EW_AXPY, [dout, d], [t], coef=1.0), ops.ew(L.EW_AXPY, [t, dx_b], [dx], coef=1.0)), "sum of the three paths")
+    return dx
+
+
+def _deconv_bwd(bw, pk, r: dict, dy: View, grads, need_dx: bool = True) -> Optional[View]:
+    m = r["mod"]
+    x = r["x"]
+    ci, co = m.in_channels, m.out_channels
+    gw, gb = grads[id(m.weight)], grads[id(m.bias)]
+    if dy.C == co:
+        bw.wgrad(ops.wgrad_problems([dy], x, gw, None, stride=2))
+        bw.call(lambda: ops.colsum(dy, gb), "deconv bias grad")
+    else:                                            # zero-padded 3-channel output gradient
+        tw = torch.zeros((ci, dy.C, 5, 5), dtype=torch.float32, device=gw.device)
+        tb = torch.zeros((dy.C,), dtype=torch.float32, device=gw.device)
+        bw.keep += [tw, tb]
+        bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2))
+        bw.call(lambda: (ops.colsum(dy, tb), gw.copy_(tw[:, :co]), gb.copy_(tb[:co])), "deconv bias grad + unpad")
+    if not need_dx:
+        return None
+    dx = bw.buf(x.B, x.H, x.W, ci)
+    bw.conv([ops.conv_problem(pk.d[id(m)], [dy], dx)])
+    return dx
+
+
+def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
+    g = r["mod"]
+    x, n = r["x"], r["n"]
+    s, dx0, x2 = (bw.buf(x.B, x.H, x.W, x.C) for _ in range(3))
+    bw.call(lambda: ops.ew(L.EW_GDN_BWD_PREP, [x, n, dy], [s, dx0, x2], flag=1 if g.inverse else 0), "gdn bwd prep")
+    u = bw.buf(x.B, x.H, x.W, x.C)
+    bw.conv([ops.conv_problem(pk.d[id(g)], [s], u)])
+    dx = bw.buf(x.B, x.H, x.W, x.C)
+    bw.call(lambda: ops.ew(L.EW_GDN_BWD_FIN, [dx0, x, u], [dx]), "gdn bwd fin")
+    C_ = x.C
+    tg = torch.zeros((C_, C_), dtype=torch.float32, device=x.buf.device)
+    tb = torch.zeros((C_,), dtype=torch.float32, device=x.buf.device)
+    bw.keep += [tg, tb]
+    bw.wgrad(ops.wgrad_problems([x2], s, tg, tb))                     # d gamma' [j][i] = sum dn_j x_i^2 ; d beta' = sum dn
+    gg, gbeta = grads[id(g.gamma)], grads[id(g.beta)]
+    bw.call(lambda: (ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.gamma.detach()), ops.flat_view(tg)], [ops.flat_view(gg)], coef=_GAMMA_BOUND),
+                     ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.beta.detach()), ops.flat_view(tb)], [ops.flat_view(gbeta)], coef=_BETA_BOUND)),
+            "NonNegativeParametrizer backward")
+    return dx
+
+
+def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torch.Tensor, pk: TransformPacks, grads):
+    """dL/d(parameters of the transform) from dL/dx_hat (NCHW, ``g_xhat``); nothing upstream of the transform's input is
+    trainable in this schedule (train.py:216-218)."""
+    B, _, H, W = x_hat.shape
+    gcl = torch.zeros_like(x_hat)
+    d16 = bw.buf(B, H, W, 16, zero=True)
+    bw.keep.append(gcl)
+    bw.call(lambda: (ops.ew(L.EW_CLAMP_BWD, [ops.flat_view(x_hat), ops.flat_view(g_xhat)], [ops.flat_view(gcl)]),
+                     L.check(L.load().vam_nchw_to_nhwc(gcl.data_ptr(), d16.ptr, B, 3, H, W, d16.ld, ops.stream_ptr()), "vam_nchw_to_nhwc")),
+            "clamp backward + NCHW -> NHWC")
+    d: Optional[View] = d16
+    for i, r in enumerate(reversed(tape)):
+        first = i == len(tape) - 1
+        if r["kind"] == "deconv":
+            d = _deconv_bwd(bw, pk, r, d, grads)
+        elif r["kind"] == "gdn":
+            d = _gdn_bwd(bw, pk, r, d, grads)
+        else:
+            d = _attention_block_bwd(bw, pk, r, d, grads, need_dx=not first)

@@ -264,32 +264,38 @@ class VarianceMaskingPIC(CompressionModel):
             raise ValueError("support_progressive_slices must be >= 0")
 
     def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False,
-              train: bool = False, own_ck: bool = False) -> "_FsqPlan":
+              train: bool = False, own_ck: bool = False, train_gs: bool = False) -> "_FsqPlan":
         B, C_, H, W = x.shape
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
         key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ()) + \
-            (("own_ck",) if own_ck else ())
+            (("own_ck",) if own_ck else ()) + (("train_gs",) if train_gs else ())
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
-        wsig = self._weights_sig()
+        wsig = self._weights_sig(self._decoder_in_use(base_only) if train_gs else None)
         if p is not None and p.wsig != wsig:
             p = None                # a parameter was edited in place (param.data.copy_, nn.init, optimizer step)
         if p is None:
-            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck)
+            p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck,
+                         train_gs=train_gs)
             p.wsig = wsig
             self._plans[key] = p
         return p
 
-    def _weights_sig(self):
-        """(_version, data_ptr) of every parameter the plans pack ONCE (everything except ``post_latent``, whose
-        training plans re-pack in place every step and whose eval plans carry ``rem_sig``): a plan built before an
-        in-place edit of a weight must not be replayed."""
-        ps = self.__dict__.get("_sig_params")
+    def _decoder_in_use(self, base_only: bool):
+        return (self.g_s[0 if base_only else 1] if self.multiple_decoder else self.g_s)
+
+    def _weights_sig(self, trained: Optional[nn.Module] = None):
+        """(_version, data_ptr) of every parameter the plans pack ONCE (everything except ``post_latent`` — and except
+        ``trained``, the transform a training plan re-packs in place every step): a plan built before an in-place edit
+        of a weight must not be replayed."""
+        cache = self.__dict__.setdefault("_sig_params", {})
+        ps = cache.get(id(trained))
         if ps is None:
-            ps = [p for n, p in self.named_parameters() if not n.startswith("post_latent.")]
-            self.__dict__["_sig_params"] = ps
+            skip = {id(p) for p in trained.parameters()} if trained is not None else set()
+            ps = [p for n, p in self.named_parameters() if not n.startswith("post_latent.") and id(p) not in skip]
+            cache[id(trained)] = ps
         h = 0
         for p in ps:
             h = (h * 1000003 + p._version * 31 + (p.data_ptr() >> 4)) & 0xFFFFFFFFFFFFFFF
@@ -304,10 +310,17 @@ class VarianceMaskingPIC(CompressionModel):
         are STE-rounded, so every other output equals the eval pass) — VALUES only: the transforms outside the REMs have
         no backward kernels in this build, so asking for their gradients fails loudly instead of silently
         returning none.  ``noise`` = {"y": NCHW, "z": NCHW} injects fixed draws."""
+        train_gs = False
         if training and torch.is_grad_enabled() and self._trainable_outside_rem():
-            raise NotImplementedError("training-mode forward outside the REMs needs the backward kernels of g_a / g_s / "
-                                      "hyperprior / slice stacks (SURVEY K14), not built yet: call under torch.no_grad() "
-                                      f"or freeze {self._trainable_outside_rem()[:2]}...")
+            # `--training_type refine_gs` (train.py:150-157,216-218): only the synthesis transform in use trains
+            dec_ids = {id(p) for p in self._decoder_in_use(quality == 0).parameters()}
+            other = [n for n, p in self.named_parameters()
+                     if p.requires_grad and not n.startswith("post_latent.") and id(p) not in dec_ids]
+            if other or not self.all_scalable:
+                raise NotImplementedError("backward kernels exist for the synthesis transform (refine_gs: freeze_all(); "
+                                          "unfreeze_decoder()) and the REMs; gradients of g_a / hyperprior / slice stacks "
+                                          f"(SURVEY K14) are not built yet — trainable outside: {other[:3]}")
+            train_gs = True
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
             raise NotImplementedError()
@@ -322,8 +335,13 @@ class VarianceMaskingPIC(CompressionModel):
             sub = lambda i: None if noise is None else {k: v[i:i + nb] for k, v in noise.items()}
             return _cat_outputs([self.forward_single_quality(x[i:i + nb], quality, mask_pol, training, True, sub(i))
                                  for i in range(0, x.shape[0], nb)])
-        plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training))
-        return plan.execute(x.detach(), pr, None, self.use_graph, clone, noise=noise)
+        if train_gs and x.shape[0] > nb:
+            raise NotImplementedError("refine_gs training: batch larger than one plan's 32-bit addressing range")
+        plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training), train_gs=train_gs)
+        out = plan.execute(x.detach(), pr, None, self.use_graph, clone, noise=noise)
+        if train_gs:
+            out["x_hat"] = _GsTrainFn.apply(plan, out["x_hat"], self.use_graph, *plan.gs_params)
+        return out
 
     def forward(self, x, quality=None, mask_pol=None, training=True, noise=None):
         """models/pic.py:301-491: the base pass plus one progressive pass per requested quality (default [0, 10]),
@@ -684,12 +702,31 @@ class _RemTrainFn(torch.autograd.Function):
         return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[3:]))
 
 
+class _GsTrainFn(torch.autograd.Function):
+    """x_hat of the training-mode forward as a differentiable function of the synthesis transform's parameters (the only
+    trainable ones under ``--training_type refine_gs``, train.py:216-218)."""
+
+    @staticmethod
+    def forward(ctx, plan, x_hat, use_graph, *params):
+        ctx.plan, ctx.use_graph, ctx.generation = plan, use_graph, plan.generation
+        return x_hat.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError("the training plan for this shape ran again before this backward(): its tape now belongs to "
+                               "the later forward — call loss.backward() before the next training forward of this shape")
+        grads = ctx.plan.backward_gs(g.contiguous(), ctx.use_graph)
+        return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
 class _FsqPlan:
     """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
 
     def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False, train=False,
-                 own_ck=False):
+                 own_ck=False, train_gs=False):
         self.m, self.B, self.H, self.W = m, B, H, W
+        self.train_gs = train_gs    # the synthesis transform in use is being trained (refine_gs): taped g_s + backward plan
         self.own_ck, self.ck_pr = own_ck, 0.0     # fine-tune: derive the checkpoint latent inside this plan
         self.base_only, self.rem_idx = base_only, rem_idx
         self.symbols = symbols
@@ -791,7 +828,10 @@ class _FsqPlan:
         if base_only:
             if not symbols:                              # compress() does not decode (pic.py:671-860)
                 plan.set_class("g_s")
-                E.lower_g_s(plan, [m.g_s[0] if m.multiple_decoder else m.g_s], [yb], [self.x_hat])
+                if train_gs:
+                    self._lower_g_s_train(plan, m.g_s[0] if m.multiple_decoder else m.g_s, yb)
+                else:
+                    E.lower_g_s(plan, [m.g_s[0] if m.multiple_decoder else m.g_s], [yb], [self.x_hat])
             return
 
         # ---- progressive slices                                                    pic.py:577-643
@@ -911,7 +951,49 @@ class _FsqPlan:
                        [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
         if not symbols:
             plan.set_class("g_s")
-            E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
+            if train_gs:
+                self._lower_g_s_train(plan, g_s, yp)
+            else:
+                E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
+
+    def _lower_g_s_train(self, plan, dec, y_in):
+        """refine_gs: taped synthesis transform + its backward plan (gs_train.py)."""
+        from . import gs_train as G
+        dev = self.x_in.device
+        self.gs_params = list(dec.parameters())
+        self.gs_packs = G.TransformPacks(dec)
+        self.gs_packs.record_refresh(plan)
+        tape = G.lower_g_s_train(plan, dec, y_in, self.x_hat, self.gs_packs)
+        bw = self.gs_bwd = E.Plan(dev)
+        self.g_xhat = torch.zeros_like(self.x_hat)
+        offs, tot = [], 0
+        for p in self.gs_params:                       # every gradient view 16-byte aligned inside one flat bucket
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        self.gs_flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.gs_views = [self.gs_flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.gs_params)]
+        grads = {id(p): g for p, g in zip(self.gs_params, self.gs_views)}
+        bw.keep += [self.g_xhat, self.gs_flat, self.gs_views]
+        G.lower_g_s_backward(bw, tape, self.x_hat, self.g_xhat, self.gs_packs, grads)
+
+    def backward_gs(self, grad_x_hat: torch.Tensor, use_graph: bool):
+        """dL/d(parameters of the trained synthesis transform) for dL/dx_hat; fresh tensors in ``gs_params`` order."""
+        cur = torch.cuda.current_stream(self.x_in.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.g_xhat.copy_(grad_x_hat)
+            if use_graph:
+                if getattr(self, "_gs_bwd_graph", None) is None:
+                    self.gs_bwd.run()
+                    self.stream.synchronize()
+                    self._gs_bwd_graph = ops.Graph()
+                    self._gs_bwd_graph.capture(self.gs_bwd.run)
+                self._gs_bwd_graph.launch()
+            else:
+                self.gs_bwd.run()
+            out = [v.clone() for v in self.gs_views]
+        cur.wait_stream(self.stream)
+        return out
 
     def _lower_prog_sequential(self, plan, heads, means_h, scales_h, hyper_done, supports, y_top, y_sub, yb, yp, ls_y,
                                table, symbols):
@@ -995,6 +1077,12 @@ class _FsqPlan:
         self.pr = float(pr)
         self.generation += 1
         self.ck_pr = float(ck_pr) if ck_pr is not None else 0.0
+        if self.train_gs:
+            sig = tuple(p.data_ptr() for p in self.gs_params)
+            if getattr(self, "_gs_ptr_sig", sig) != sig:       # parameter storage replaced: captured pointers are stale
+                self.graphs.clear()
+                self._gs_bwd_graph = None
+            self._gs_ptr_sig = sig
         if self.train and self.rem_idx is not None:
             sig = tuple(p.data_ptr() for p in self.rem_params)
             if getattr(self, "_ptr_sig", sig) != sig:          # parameter storage replaced: captured pointers are stale

@@ -402,18 +402,24 @@ def pack_conv_dgrad(weight: torch.Tensor) -> Packed:
     return Packed(w, None, kh, kw, n_out, c_in, 1, kh // 2, kw // 2)
 
 
-def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor]) -> List[L.VamWgrad]:
-    """dw (OIHW) / db of a stride-1 conv whose input was the channel concat of ``x_segs``: one problem per segment."""
-    n, cin_total, kh, kw = dw.shape
+def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optional[torch.Tensor],
+                   stride: int = 1) -> List[L.VamWgrad]:
+    """dw (OIHW) / db of a conv (stride 1 pad k/2, or the k5/s2/p2 one) whose input was the channel concat of
+    ``x_segs``: one problem per segment.  dw may be a 2-D [N, C] tensor (a 1x1 layer / nn.Linear)."""
+    if dw.dim() == 2:
+        n, cin_total, kh, kw = dw.shape[0], dw.shape[1], 1, 1
+    else:
+        n, cin_total, kh, kw = dw.shape
     assert dy.C == n and sum(v.C for v in x_segs) == cin_total and dw.is_contiguous() and kh == kw
     out, off = [], 0
     for v in x_segs:
-        assert (v.B, v.H, v.W) == (dy.B, dy.H, dy.W)
+        assert v.B == dy.B and (v.H, v.W) == (stride * dy.H, stride * dy.W)
         p = L.VamWgrad()
         p.x, p.dy, p.dw = v.ptr, dy.ptr, dw.data_ptr()
         p.db = db.data_ptr() if (db is not None and off == 0) else None
-        p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, v.B, v.H, v.W, kh, kw, v.C, n
+        p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, dy.B, dy.H, dy.W, kh, kw, v.C, n
         p.cin_total, p.c_off = cin_total, off
+        p.stride, p.Hx, p.Wx = stride, v.H, v.W
         out.append(p)
         off += v.C
     return out
@@ -446,6 +452,50 @@ def gauss_train(y: View, mu: View, sigma: View, noise: View, *, y2: Optional[Vie
     def p(v): return (v.ptr, v.ld) if v is not None else (None, 0)
     L.check(L.load().vam_gauss_train(*p(y), *p(y2), *p(mu), *p(sigma), *p(mask), *p(noise), *p(grad_lik), *p(lik),
                                      *p(dmu), *p(dsigma), y.n_pix, y.C, stream_ptr()), "vam_gauss_train")
+
+
+# ---- transform backward pieces (csrc/train_gs.hip)
+def ew(op: int, ins: Sequence[View], outs: Sequence[View], coef: float = 0.0, flag: int = 0):
+    """One element-wise derivative kernel (enum vam_ew_op) over channel windows of equal extent."""
+    e = L.VamEw()
+    v0 = ins[0]
+    for k, v in enumerate(ins):
+        assert v.n_pix == v0.n_pix and v.C == v0.C
+        e.inp[k].ptr, e.inp[k].ld = v.ptr, v.ld
+    for k, v in enumerate(outs):
+        assert v.n_pix == v0.n_pix and v.C == v0.C
+        e.out[k].ptr, e.out[k].ld = v.ptr, v.ld
+    e.n_pix, e.C, e.flag, e.coef = v0.n_pix, v0.C, int(flag), float(coef)
+    L.check(L.load().vam_train_elementwise(op, C.byref(e), stream_ptr()), "vam_train_elementwise")
+
+
+def flat_view(t: torch.Tensor, width: int = 4) -> View:
+    """A contiguous fp32 tensor of any shape as an [n/width, width] channel window (element-wise kernels only)."""
+    assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() % width == 0
+    return View(t.view(1, 1, t.numel() // width, width), 0, width)
+
+
+def win_attention_bwd(qkv: View, dout: View, dqkv: View, table: torch.Tensor, dtable: torch.Tensor, C_: int, heads: int,
+                      ws: int, shift: int):
+    assert dtable.shape == table.shape and dtable.is_contiguous()
+    L.check(L.load().vam_win_attention_bwd(qkv.ptr, qkv.ld, dout.ptr, dout.ld, dqkv.ptr, dqkv.ld, table.data_ptr(),
+                                           dtable.data_ptr(), qkv.B, qkv.H, qkv.W, C_, heads, ws, shift, stream_ptr()),
+            "vam_win_attention_bwd")
+
+
+def colsum(dy: View, out: torch.Tensor):
+    L.check(L.load().vam_colsum(dy.ptr, dy.ld, dy.n_pix, dy.C, out.data_ptr(), stream_ptr()), "vam_colsum")
+
+
+def repack_weights(src: torch.Tensor, dst: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int):
+    """vam_pack_conv_weights into an EXISTING packed buffer (training: the optimiser changed ``src`` in place)."""
+    assert src.is_cuda and src.is_contiguous() and src.dtype == torch.float32
+    L.check(L.load().vam_pack_conv_weights(src.data_ptr(), dst.data_ptr(), mode, phase, kh, kw, cin, n, stream_ptr()),
+            "vam_pack_conv_weights")
+
+
+def repack_bias(src: torch.Tensor, dst: torch.Tensor, mode: int, n: int):
+    L.check(L.load().vam_pack_bias(src.data_ptr(), dst.data_ptr(), mode, n, stream_ptr()), "vam_pack_bias")
 
 
 def memset_zero(t: torch.Tensor):

@@ -121,9 +121,11 @@ enum vam_pack_mode {
                             packed n = (i*2+j)*Cq + c   (layers/layers.py:82-86)          */
   VAM_PACK_GDN = 3,      /* src gamma [N][Cin] in reparametrised storage -> max(g,2^-18)^2-2^-36
                             (layers/gdn.py:52-66, compressai NonNegativeParametrizer)     */
-  VAM_PACK_CONV_DGRAD = 4/* weights of the DATA-GRADIENT conv of a stride-1 nn.Conv2d: src is the forward
+  VAM_PACK_CONV_DGRAD = 4,/* weights of the DATA-GRADIENT conv of a stride-1 nn.Conv2d: src is the forward
                             OIHW tensor [Cout][Cin][kh][kw]; call with cin = Cout, n = Cin (taps flipped,
                             channel roles swapped) — what autograd's conv backward-data computes          */
+  VAM_PACK_GDN_T = 5     /* VAM_PACK_GDN with the reparametrised gamma TRANSPOSED: the 1x1 problem that carries
+                            dL/dnorm back to the squared inputs (GDN / IGDN backward)                       */
 };
 /* Device-side repack of a weight tensor into the kernel's [tap][k-chunk][n][k] layout. */
 int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase,
@@ -251,10 +253,13 @@ typedef struct vam_wgrad {
   float* dw;
   float* db;
   int ld_x, ld_dy;
-  int B, H, W;
+  int B, H, W;        /* extent of dy (the convolution's output grid)                                          */
   int kh, kw;
   int C, N;
   int cin_total, c_off;
+  int stride;         /* 0 or 1: stride 1, pad k/2, x has the extent of dy.  2: the k5/s2/p2 convolution — x is   */
+  int Hx, Wx;         /* [B, Hx, Wx] (Hx = 2H, Wx = 2W): input pixel = 2*o - 2 + tap.  Used for the transposed     */
+                      /* convolutions of g_s, whose weight gradient is this with the roles of x and dy exchanged    */
 } vam_wgrad;
 int vam_conv_wgrad_group(const vam_wgrad* problems, int n_problems, void* stream);
 int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw,
@@ -272,6 +277,37 @@ int vam_gauss_train(const float* y, int ld_y, const float* y2, int ld_y2, const 
                     const float* sigma, int ld_sigma, const float* mask, int ld_mask, const float* noise, int ld_noise,
                     const float* grad_lik, int ld_glik, float* lik, int ld_lik, float* dmu, int ld_dmu,
                     float* dsigma, int ld_dsigma, long n_pix, int C, void* stream);
+
+/* ------------------------------------------------------------------ transform backward (refine_gs) */
+/* Element-wise derivatives of the synthesis / analysis transforms (csrc/train_gs.hip).  Every tensor is a channel
+ * window [n_pix, C] with its own pixel stride. */
+enum vam_ew_op {
+  VAM_EW_GELU_FWD = 0,      /* out0 = gelu(in0)                                          (layers/layers.py:36-40) */
+  VAM_EW_GELU_BWD = 1,      /* in0 = pre-activation, in1 = dy: out0 = dy * gelu'(in0)                                 */
+  VAM_EW_GATE_BWD = 2,      /* a*sigmoid(b)+x (layers.py:72-74): in0 = a, in1 = b, in2 = dout: out0 = da, out1 = db    */
+  VAM_EW_GDN_APPLY = 3,     /* in0 = x, in1 = norm: out0 = x*sqrt(norm) (flag 1, IGDN) or x*rsqrt(norm) (gdn.py:70-72) */
+  VAM_EW_GDN_BWD_PREP = 4,  /* in0 = x, in1 = norm, in2 = dy: out0 = dL/dnorm, out1 = dy * dy/dx at fixed norm, out2 = x^2 */
+  VAM_EW_GDN_BWD_FIN = 5,   /* in0 = out1 above, in1 = x, in2 = gamma^T dL/dnorm: out0 = in0 + 2 x in2                  */
+  VAM_EW_CLAMP_BWD = 6,     /* in0 = clamp_(v,0,1), in1 = dL/dout: out0 = dL/dv                      (pic.py:558,651) */
+  VAM_EW_AXPY = 7,          /* out0 = in0 + coef * in1                                                                 */
+  VAM_EW_GATE_FWD = 8,      /* in0 = a, in1 = b, in2 = x: out0 = a*sigmoid(b) + x                                      */
+  VAM_EW_REPARAM_BWD = 9    /* NonNegativeParametrizer backward: in0 = stored parameter, in1 = dL/dvalue, coef = bound */
+};
+typedef struct vam_ew {
+  vam_aux in[4];
+  vam_aux out[3];
+  long n_pix;
+  int32_t C;
+  int32_t flag;
+  float coef;
+  int32_t pad_;
+} vam_ew;
+int vam_train_elementwise(int op, const vam_ew* e, void* stream);
+/* Backward of vam_win_attention: dqkv [B,H,W,3C] (dq | dk | dv, same layout as qkv) from dout = dL/d(attention output),
+ * and the relative-position-bias gradient ACCUMULATED into dtable [(2ws-1)^2][heads] (clear it first). */
+int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int ld_do, float* dqkv, int ld_dq,
+                          const float* table, float* dtable, int B, int H, int W, int C, int heads, int ws, int shift,
+                          void* stream);
 
 /* ------------------------------------------------------------------ bitstream (HOST pointers) */
 /* compressai `_CXX.pmf_to_quantized_cdf` (reference entropy_models.py:61-64): n probabilities ->

@@ -274,6 +274,35 @@ def main():
     with open(os.path.join(GOLD, "demo_256.json"), "w") as f:
         json.dump(scal, f, indent=1)
 
+    # 8b. decoder refinement step (`--training_type refine_gs`, train.py:150-157,216-218): the reference's own
+    #     training-mode forward, DistortionLoss (training/loss.py:126-187) and backward with only g_s[1] trainable.
+    spec = importlib.util.spec_from_file_location("ref_training_loss2", os.path.join(REF, "training", "loss.py"))
+    loss_mod2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loss_mod2)
+    pic.train()
+    pic.freeze_all()
+    pic.unfreeze_decoder()
+    xr = synth.synth_image(1, 64, 64, seed=3)
+    torch.manual_seed(1)                                    # the likelihood noise (unused by the distortion loss)
+    o = pic.forward_single_quality(xr, quality=2.5, training=True)
+    crit = loss_mod2.DistortionLoss(device="cpu")(o, xr)
+    crit["loss"].backward()
+    rec = {"loss": np.array([crit["loss"].item(), crit["mse_loss"].item()], dtype=np.float64),
+           "x_hat": o["x_hat"].detach()[:, :, ::2, ::2].numpy()}
+    names, norms, samples = [], [], []
+    for k, p_ in pic.g_s[1].named_parameters():
+        gflat = p_.grad.detach().reshape(-1)
+        names.append(k)
+        norms.append(gflat.double().norm().item())
+        samples.append(gflat[::97].numpy())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms, dtype=np.float64)
+    rec["grad_samples"] = np.concatenate(samples).astype(np.float32)      # every 97th element of each gradient
+    others = [k for k, p_ in pic.named_parameters() if p_.grad is not None and not k.startswith("g_s.1.")]
+    assert not others, others
+    np.savez_compressed(os.path.join(GOLD, "refine_gs_step.npz"), **rec)
+    pic.eval()
+
     # 9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each
     #    (q = 0 and q = 2.5; REM variants with a checkpoint latent at their first check level).  Weights: the same
     #    name-keyed synthetic generator, so the shared modules carry the same values in every variant.

@@ -201,8 +201,8 @@ def eb_forward(sd: SD, z: Tensor, prefix: str = "entropy_bottleneck."):
 def nonneg(p: Tensor, minimum: float) -> Tensor:
     """compressai NonNegativeParametrizer.forward."""
     pedestal = torch.tensor([(2.0 ** -18) ** 2], dtype=torch.float32)
-    bound = torch.tensor([(minimum + (2.0 ** -18) ** 2) ** 0.5], dtype=torch.float32)
-    return torch.max(p, bound) ** 2 - pedestal
+    # LowerBound (not a plain max): same value, and compressai's gradient rule when the parameters train (A.3)
+    return lower_bound(p, (minimum + (2.0 ** -18) ** 2) ** 0.5) ** 2 - pedestal
 
 
 def gdn(sd: SD, pre: str, x: Tensor, inverse: bool) -> Tensor:
@@ -636,3 +636,23 @@ def rem_training_step(sd: SD, x: Tensor, quality: float, checkpoint_ref: Tensor,
     return {"likelihoods": {"y": lik_y.detach(), "z": z_lik}, "loss": float(loss.detach()),
             "grads": {k: v.grad for k, v in leaves.items()}, "mask": torch.cat(masks, 1),
             "mu": torch.cat(mu_f, 1).detach(), "std": torch.cat(std_f, 1).detach()}
+
+
+# --------------------------------------------------------------------------
+# A.10 decoder refinement step (train.py:150-157,216-218 `--training_type refine_gs`): everything frozen except the
+#      synthesis transform of the progressive decoder; DistortionLoss (training/loss.py:126-187)
+# --------------------------------------------------------------------------
+def refine_gs_training_step(sd: SD, x: Tensor, quality: float, *, lmbda: float = 1e-2, weight: float = 255.0 ** 2,
+                            prefix: str = "g_s.1.", **flags):
+    """One ``refine_gs`` step: the frozen front end gives y_hat (its STE-rounded values equal the eval pass, pic.py:629),
+    x_hat = g_s[1](y_hat).clamp(0, 1), loss = weight * lmbda * mean((x - x_hat)^2).  Returns (loss, mse, x_hat,
+    {name: gradient}) for the parameters under ``prefix``."""
+    y_hat = forward_single_quality(sd, x, quality, **flags)["y_hat"].detach()
+    leaves = {k: (v.clone().requires_grad_(True) if k.startswith(prefix) and v.dtype.is_floating_point else v)
+              for k, v in sd.items()}
+    x_hat = g_s(leaves, prefix, y_hat).clamp(0, 1)
+    mse = F.mse_loss(x, x_hat)
+    loss = weight * (lmbda * mse)
+    loss.backward()
+    grads = {k[len(prefix):]: v.grad for k, v in leaves.items() if k.startswith(prefix) and torch.is_tensor(v) and v.grad is not None}
+    return loss.detach(), mse.detach(), x_hat.detach(), grads

@@ -7,6 +7,12 @@ for r in 1 2; do
   VAMPIC_SPEC=0 timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/spec_A_$r.log 2>&1
   VAMPIC_SPEC=1 timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/spec_B_$r.log 2>&1
 done
+FORCE_TILE=64,192 VAMPIC_SPEC=0 timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/spec_F0.log 2>&1
+FORCE_TILE=64,192 VAMPIC_SPEC=1 timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/spec_F1.log 2>&1
+FORCE_TILE=128,128 VAMPIC_SPEC=1 timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/spec_G1.log 2>&1
+echo "--- forced 64x192 one-role"; cat gpurun_out/spec_F0.log | grep tile
+echo "--- forced 64x192 spec"; cat gpurun_out/spec_F1.log | grep tile
+echo "--- forced 128x128 spec"; cat gpurun_out/spec_G1.log | grep tile
 python - <<'PY'
 import re
 rows={}

@@ -15,6 +15,10 @@ SHAPES = [  # (n_problems, cin, n, k, stride, B, H, W, p3_in)
     (2, 16, 192, 3, 1, 32, 128, 128, 0),
 ]
 lib = L.load()
+if os.environ.get("FORCE_TILE"):
+    bm_, bn_ = (int(v) for v in os.environ["FORCE_TILE"].split(","))
+    lib.vam_conv_force_tile(bm_, bn_, 32)
+    SHAPES = [sh for sh in SHAPES if sh[2] % bn_ == 0 or sh[2] > bn_][:4] + SHAPES[11:12]
 for npb, cin, n, k, st, B, H, W, p3 in SHAPES:
     probs, keep = [], []
     for i in range(npb):

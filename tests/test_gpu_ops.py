@@ -297,7 +297,7 @@ def test_entropy_bottleneck_aux_loss_and_gradient():
     from vampic.entropy_models import EntropyBottleneck
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "entropy_ops.npz"))
     eb = EntropyBottleneck(192)
-    eb.load_state_dict(synth.synth_state_dict(eb.state_dict(), 40))
+    eb.load_state_dict(vampic.synth.synth_state_dict(eb.state_dict(), 40))
     eb = eb.cuda()
     loss = eb.loss()
     loss.backward()

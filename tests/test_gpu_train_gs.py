@@ -1,0 +1,232 @@
+"""Decoder refinement (`--training_type refine_gs`, reference train.py:150-157,216-218; SURVEY K14 first schedule) on the
+GPU: the backward kernels of the synthesis transform against torch autograd over the oracle, the full step against the
+gradients the REFERENCE computed (tests/golden/refine_gs_step.npz)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import vampic                              # noqa: E402
+import vampic.synth as synth               # noqa: E402
+import vampic_oracle as O                  # noqa: E402
+from vampic import _lib as L               # noqa: E402
+from vampic import engine as E, gs_train as G, layers as Ly, ops    # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_elementwise_derivatives_match_autograd():
+    shp = (2, 32, 4, 8)
+    x = synth.normal(shp, 1, 2.0).requires_grad_(True)
+    g = synth.normal(shp, 2)
+    V = lambda t: ops.from_nchw(t.detach().cuda())
+    N = lambda: ops.new_view(2, 4, 8, 32)
+    # exact-erf GELU
+    F.gelu(x).backward(g)
+    o, d = N(), N()
+    ops.ew(L.EW_GELU_FWD, [V(x)], [o])
+    ops.ew(L.EW_GELU_BWD, [V(x), V(g)], [d])
+    assert _rel(o.torch_nchw(), F.gelu(x)) <= 1e-6 and _rel(d.torch_nchw(), x.grad) <= 1e-5
+    # sigmoid gate a * sigmoid(b) + x
+    a = synth.normal(shp, 3).requires_grad_(True)
+    b = synth.normal(shp, 4, 3.0).requires_grad_(True)
+    xs = synth.normal(shp, 5)
+    (a * torch.sigmoid(b) + xs).backward(g)
+    da, db, fo = N(), N(), N()
+    ops.ew(L.EW_GATE_FWD, [V(a), V(b), V(xs)], [fo])
+    ops.ew(L.EW_GATE_BWD, [V(a), V(b), V(g)], [da, db])
+    assert _rel(fo.torch_nchw(), a * torch.sigmoid(b) + xs) <= 1e-6
+    assert _rel(da.torch_nchw(), a.grad) <= 1e-5 and _rel(db.torch_nchw(), b.grad) <= 1e-5
+    # clamp_(0, 1) backward from the clamped value
+    v = (synth.normal(shp, 6) * 0.7 + 0.5).requires_grad_(True)
+    v.clamp(0, 1).backward(g)
+    dv = N()
+    ops.ew(L.EW_CLAMP_BWD, [V(v.clamp(0, 1)), V(g)], [dv])
+    assert torch.equal(dv.torch_nchw().cpu(), v.grad)
+
+
+@pytest.mark.parametrize("dim,ws,hw", [(192, 8, (16, 24)), (320, 4, (8, 8))])
+def test_attention_block_backward(dim, ws, hw):
+    """Win_noShift_Attention (residual units, Swin block with shift / mask / relative-position bias, sigmoid gate): taped
+    forward + backward lowering against autograd over the oracle's attention_block: output 1e-5, input gradient and every
+    parameter gradient 5e-5 of their max."""
+    B = 2
+    m = Ly.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=ws // 2)
+    sd = synth.synth_state_dict(m.state_dict(), 9)
+    m.load_state_dict(sd)
+    m.cuda()
+    x = synth.normal((B, dim) + hw, 10)
+    dy = synth.normal((B, dim) + hw, 11)
+    plan, bw = E.Plan("cuda"), E.Plan("cuda")
+    pk = G.TransformPacks(m)
+    pk.record_refresh(plan)
+    tape = []
+    out = G._attention_block_fwd(plan, pk, m, ops.from_nchw(x.cuda()), tape)
+    grads = {id(p): torch.full_like(p, float("nan")) for p in m.parameters()}
+    dx = G._attention_block_bwd(bw, pk, tape[0], ops.from_nchw(dy.cuda()), grads, need_dx=True)
+    plan.run()
+    bw.run()
+    torch.cuda.synchronize()
+    leaves = {"m." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.attention_block(leaves, "m.", xr, ws)
+    ref.backward(dy)
+    assert _rel(out.torch_nchw(), ref) <= 1e-5
+    assert _rel(dx.torch_nchw(), xr.grad) <= 5e-5
+    for n, p in m.named_parameters():
+        assert _rel(grads[id(p)], leaves["m." + n].grad) <= 5e-5, (n, _rel(grads[id(p)], leaves["m." + n].grad))
+
+
+@pytest.mark.parametrize("cout", [192, 3])
+def test_deconv_and_igdn_backward(cout):
+    """ConvTranspose2d(k5, s2, p2, op1) (data gradient = a k5/s2 convolution, weight gradient = stride-2 wgrad with the
+    roles exchanged) and IGDN incl. the NonNegativeParametrizer chain, against autograd over the oracle."""
+    B, cin, H, W = 2, 192, 6, 8
+    dec = Ly.ConvTranspose2d(cin, cout).cuda()
+    sd_d = synth.synth_state_dict(dec.state_dict(), 21)
+    dec.load_state_dict(sd_d)
+    x = synth.normal((B, cin, H, W), 22)
+    plan, bw = E.Plan("cuda"), E.Plan("cuda")
+    mods = torch.nn.Sequential(dec) if cout == 3 else torch.nn.Sequential(dec, Ly.GDN(cout, inverse=True).cuda())
+    if cout != 3:
+        sd_g = synth.synth_state_dict(mods[1].state_dict(), 23)
+        mods[1].load_state_dict(sd_g)
+    pk = G.TransformPacks(mods)
+    pk.record_refresh(plan)
+    tape = []
+    t = G._deconv_fwd(plan, pk, dec, ops.from_nchw(x.cuda()), tape)
+    if cout != 3:
+        t = G._gdn_fwd(plan, pk, mods[1], t, tape)
+    dy = synth.normal((B, cout, 2 * H, 2 * W), 24)
+    grads = {id(p): torch.full_like(p, float("nan")) for p in mods.parameters()}
+    if cout == 3:                                   # the model's last layer: 3-channel gradient, zero-padded to 16
+        d16 = ops.new_view(B, 2 * H, 2 * W, 16, zero=True)
+        d16.buf[..., :3].copy_(dy.cuda().permute(0, 2, 3, 1))
+        d = d16
+    else:
+        d = ops.from_nchw(dy.cuda())
+        d = G._gdn_bwd(bw, pk, tape[1], d, grads)
+    dx = G._deconv_bwd(bw, pk, tape[0], d, grads)
+    plan.run()
+    bw.run()
+    torch.cuda.synchronize()
+    leaves = {"d." + k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
+    xr = x.clone().requires_grad_(True)
+    y = O.deconv_k(leaves, "d.", xr)
+    if cout != 3:
+        leaves.update({"g." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_g.items()})
+        y = O.gdn(leaves, "g.", y, True)
+    y.backward(dy)
+    assert _rel(t.torch_nchw(), y) <= 1e-5
+    assert _rel(dx.torch_nchw(), xr.grad) <= 5e-5
+    for n, p in dec.named_parameters():
+        assert _rel(grads[id(p)], leaves["d." + n].grad) <= 5e-5, n
+    if cout != 3:
+        for n, p in mods[1].named_parameters():
+            assert _rel(grads[id(p)], leaves["g." + n].grad) <= 5e-5, (n, _rel(grads[id(p)], leaves["g." + n].grad))
+
+
+@pytest.fixture(scope="module")
+def pic_model():
+    import argparse
+    from conftest import README_ARGS
+    net = vampic.get_model(argparse.Namespace(model="pic", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    net.load_state_dict(sd)
+    return net.cuda(), sd
+
+
+def _distortion_loss(out, x, lmbda=1e-2, weight=255.0 ** 2):
+    """training/loss.py:126-187 (DistortionLoss): weight * lmbda * mse."""
+    return weight * (lmbda * F.mse_loss(x, out["x_hat"]))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_refine_gs_step_matches_reference_gradients(pic_model, use_graph):
+    """One refine_gs step (freeze_all(); unfreeze_decoder(); training-mode forward; DistortionLoss; backward) against
+    the REFERENCE's own run (tests/golden/refine_gs_step.npz): loss 1e-5 relative; every gradient tensor within 2e-3 of
+    its norm, all sampled entries jointly within 5e-4 (the frozen front end feeds a y_hat that differs from the CPU's by
+    fp32 summation order; g_s itself is held to 5e-5 by the teacher-forced tests above)."""
+    net0, sd = pic_model
+    m = copy.deepcopy(net0).train()
+    m.use_graph = use_graph
+    m.freeze_all()
+    m.unfreeze_decoder()
+    gold = np.load(os.path.join(GOLD, "refine_gs_step.npz"))
+    x = synth.synth_image(1, 64, 64, seed=3).cuda()
+    for rep in range(2):                                          # the second pass replays the captured graphs
+        m.zero_grad(set_to_none=True)
+        out = m.forward_single_quality(x, quality=2.5, training=True)
+        loss = _distortion_loss(out, x)
+        loss.backward()
+        assert abs(float(loss.detach()) - gold["loss"][0]) <= 1e-5 * gold["loss"][0], (float(loss), gold["loss"][0])
+        assert np.abs(out["x_hat"].detach().cpu()[:, :, ::2, ::2].numpy() - gold["x_hat"]).max() <= 1e-4
+        params = dict(m.g_s[1].named_parameters())
+        off, num, den, worst = 0, 0.0, 0.0, 0.0
+        for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+            g = params[str(name)].grad.reshape(-1).cpu()
+            s_ = g[::97].numpy()
+            ref = gold["grad_samples"][off:off + len(s_)]
+            off += len(s_)
+            assert abs(float(g.double().norm()) - norm) <= 2e-3 * norm + 1e-12, (name, float(g.double().norm()), norm)
+            worst = max(worst, float(np.abs(s_ - ref).max()) / (norm + 1e-30))
+            num += float(((s_ - ref).astype(np.float64) ** 2).sum())
+            den += float((ref.astype(np.float64) ** 2).sum())
+        print(f"refine_gs gradients: joint relative error {(num / den) ** 0.5:.2e}, worst entry / norm {worst:.2e}")
+        assert (num / den) ** 0.5 <= 5e-4
+        assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("g_s.1."))
+
+
+def test_refine_gs_teacher_forced_and_loop(pic_model):
+    """(a) the step's gradients against autograd over the ORACLE's g_s fed the plan's own y_hat (teacher-forced: 5e-5);
+    (b) the reference's loop shape (training/step.py:56-99: forward, loss, backward, clip, Adam) lowers the distortion on
+    a fixed batch, leaves every frozen parameter untouched, and the eval plan sees the new weights."""
+    net0, sd = pic_model
+    m = copy.deepcopy(net0).train()
+    m.freeze_all()
+    m.unfreeze_decoder()
+    x = synth.synth_image(2, 64, 128, seed=5).cuda()
+    out = m.forward_single_quality(x, quality=1.5, training=True)
+    loss = _distortion_loss(out, x)
+    loss.backward()
+    leaves = {k: (v.clone().requires_grad_(True) if k.startswith("g_s.1.") and v.dtype.is_floating_point else v) for k, v in sd.items()}
+    xh = O.g_s(leaves, "g_s.1.", out["y_hat"].detach().cpu()).clamp(0, 1)
+    ref_loss = 255.0 ** 2 * (1e-2 * F.mse_loss(x.cpu(), xh))
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * float(ref_loss)
+    for n, p in m.g_s[1].named_parameters():
+        assert _rel(p.grad, leaves["g_s.1." + n].grad) <= 1e-4, (n, _rel(p.grad, leaves["g_s.1." + n].grad))
+    frozen = {n: p.detach().clone() for n, p in m.named_parameters() if not n.startswith("g_s.1.")}
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    with torch.no_grad():
+        before = m.forward_single_quality(x, 1.5)["x_hat"].clone()
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m.forward_single_quality(x, quality=1.5, training=True)
+        loss = _distortion_loss(out, x)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("refine_gs losses:", [round(v, 3) for v in losses])
+    assert losses[-1] < losses[0]
+    with torch.no_grad():
+        after = m.forward_single_quality(x, 1.5)["x_hat"]
+    assert not torch.equal(before, after)                         # the eval plan was rebuilt on the new weights
+    for n, p in m.named_parameters():
+        if not n.startswith("g_s.1."):
+            assert torch.equal(p, frozen[n]), n
+    m.unfreeze_encoder()                                          # anything outside the decoder still fails loudly
+    with pytest.raises(NotImplementedError):
+        m.forward_single_quality(x, quality=1.5, training=True)

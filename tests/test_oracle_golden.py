@@ -240,3 +240,28 @@ def test_oracle_aux_loss_matches_reference():
     loss.backward()
     assert abs(loss.item() - gold["eb_aux_loss"][0]) <= 1e-5 * abs(gold["eb_aux_loss"][0])
     _close(sd["entropy_bottleneck.quantiles"].grad, gold["eb_aux_dq"], 1e-5)
+
+
+def test_oracle_refine_gs_step_matches_reference():
+    """`--training_type refine_gs` (train.py:150-157,216-218): loss and every g_s[1] gradient of the oracle's step against
+    the reference's own autograd run (tests/golden/refine_gs_step.npz; incl. the NonNegativeParametrizer / LowerBound rule
+    of the IGDN parameters)."""
+    import argparse
+    import vampic
+    from conftest import README_ARGS
+    net = vampic.get_model(argparse.Namespace(model="pic", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    gold = np.load(os.path.join(GOLD, "refine_gs_step.npz"))
+    x = synth.synth_image(1, 64, 64, seed=3)
+    loss, mse, x_hat, grads = O.refine_gs_training_step(sd, x, 2.5)
+    assert abs(float(loss) - gold["loss"][0]) <= 1e-6 * gold["loss"][0] and abs(float(mse) - gold["loss"][1]) <= 1e-6 * gold["loss"][1]
+    _close(x_hat[:, :, ::2, ::2], gold["x_hat"], 2e-5)
+    off = 0
+    assert sorted(grads) == sorted(str(n) for n in gold["grad_names"])
+    for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+        g = grads[str(name)].reshape(-1)
+        s_ = g[::97].numpy()
+        ref = gold["grad_samples"][off:off + len(s_)]
+        off += len(s_)
+        assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
+        assert np.abs(s_ - ref).max() <= 1e-5 * norm + 1e-12, name
