@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--quality", type=float, default=2.5)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, the headline and every parity claim) or bf16: BASELINE configs[2] storage mode — g_a / g_s "
+                         "feature maps >= 64x64 stored in bf16, bf16-rounded weights there, fp32 accumulation; its distance to "
+                         "the fp32 path (mask XOR, dPSNR, dbpp) is measured and printed in the line")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry", action="store_true",
@@ -182,6 +186,12 @@ def main():
     from vampic import ops, _lib as L_
     net, sd = build_model(dev)
     net.use_graph = not a.no_graph
+    net32 = None
+    if a.dtype == "bf16":
+        import copy
+        net32 = net
+        net = copy.deepcopy(net)
+        net.storage = "bf16"
     B, H, W, q = a.batch, a.height, a.width, a.quality
     x = vampic.synth.synth_image(B, H, W, seed=100 + rank).to(dev)      # resident in HBM before timing
 
@@ -269,12 +279,26 @@ def main():
                                "frac": round(ga / peak, 4), "ms_per_step": round(gms / psteps, 3),
                                "flop_per_step": gfl / psteps}
 
+    vs_fp32 = None
+    if rank == 0 and net32 is not None:
+        with torch.no_grad():
+            o32 = net32.forward_single_quality(x, q, clone=True)
+            o16 = net.forward_single_quality(x, q, clone=True)
+        ps = lambda o: -10.0 * torch.log10(torch.mean((x - o["x_hat"]) ** 2)).item()
+        bp = lambda o: -o["log2_likelihood_sum"].sum().item() / (B * H * W)
+        vs_fp32 = {"reference": "the fp32 HIP path on the same weights and inputs (itself bit-exact in mask / symbols against the "
+                                "CPU oracle: tests/test_gpu_model.py)",
+                   "mask_xor": int((o16["mask"] != o32["mask"]).sum()), "mask_elements": o32["mask"].numel(),
+                   "d_psnr_db": round(ps(o16) - ps(o32), 5), "d_bpp": round(bp(o16) - bp(o32), 6),
+                   "psnr_fp32_db": round(ps(o32), 4), "bpp_fp32": round(bp(o32), 5)}
     if rank == 0:
         bpp = -out["log2_likelihood_sum"].sum().item() / (B * H * W)
         line = {"metric": "megapixels/sec encode+decode (g_a->mask->g_s) at 256x256 bs32",
                 "value": round(mp_s, 3), "unit": "MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32 (bf16x3 split operands)" if L_.load().vam_conv_get_mode() == 1 else "f32",
+                "dtype": ("bf16 storage (g_a/g_s feature maps >= 64x64 and the weights that touch them in bf16, fp32 accumulate; "
+                          "entropy-parameter stacks, variance mask, likelihoods fp32)") if a.dtype == "bf16" else
+                         ("f32 (bf16x3 split operands)" if L_.load().vam_conv_get_mode() == 1 else "f32"),
                 "data": "synthetic",
                 "config": {"workload": f"forward_single_quality q={q} on {B}x3x{H}x{W} per GPU "
                                        "(dual g_a, hyperprior, 10 base + 10 progressive slices, variance mask, "
@@ -282,6 +306,8 @@ def main():
                            "batch_per_gpu": B, "global_batch": B * world, "quality": q,
                            "hip_graph": not a.no_graph, "weights": "synthetic seed 0", "bpp_check": round(bpp, 6)},
                 "roofline": roof}
+        if vs_fp32 is not None:
+            line["vs_fp32"] = vs_fp32
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, H, W, q)
         print(json.dumps(line), flush=True)

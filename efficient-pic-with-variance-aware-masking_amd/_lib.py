@@ -18,6 +18,7 @@ VAM_MAX_GROUP = 8
 ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQRT, ACT_SQRT = range(8)
 # enum vam_conv_flags
 CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW, CONV_IN_BF3, CONV_OUT_BF3 = 1, 2, 4, 8, 16
+CONV_W_BF16, CONV_IN_BF16, CONV_OUT_BF16, CONV_AUX_BF16 = 32, 64, 128, 256      # bf16-storage mode (BASELINE configs[2])
 # enum vam_pack_mode
 PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD, PACK_GDN_T = range(6)
 # enum vam_ew_op
@@ -84,6 +85,8 @@ _SIGNATURES = {
     "vam_conv_struct_size": (C.c_size_t, []),
     "vam_conv_wpack_floats": (C.c_size_t, [C.c_int] * 4),
     "vam_pack_conv_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vam_conv_wpack_bf16_bytes": (C.c_size_t, [C.c_int] * 4),
+    "vam_pack_conv_weights_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_pack_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_conv_force_tile": (C.c_int, [C.c_int] * 3),
     "vam_conv_last_tile": (C.c_int, [C.c_void_p] * 3),

@@ -100,19 +100,23 @@ constexpr int PK = 16;  // packing granularity of the weight buffer along K
 // SIMD hosts one consumer and one loader: the matrix pipe and the vector / memory pipes run side by side instead of
 // taking turns inside each wave (measured on the 128x192 tile: MFMA-only time 1.42 ms, staging-only 1.03 ms, the
 // un-specialised kernel 2.45 ms = their SUM).  One s_barrier per K chunk.
+// (Tried on top and measured no better, so not kept: 8 consumer waves (4x2) beside 4 loaders on the 128x192 / 128x128
+// tiles — two consumers per SIMD to cover each other's operand-read latency: 2350 vs 2287 us on the 192->192 5x5 layer.)
 template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
 __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <= 192) ? 4 : 2) : 2) void conv_igemm_kernel(const GroupArgs args) {
   static_assert(SPEC == 0 || MODE == 1, "wave specialisation is built for the split-operand mode");
+  static_assert(MODE != 2 || AIN <= 1, "MODE 2: AIN 0 = fp32 input rounded while staged, 1 = bf16 input");
   constexpr int NT = WGM * WGN * 64;         // threads of one role group (= threads per block without SPEC)
+  constexpr int NTC = NT;
   constexpr int NTB = NT * (SPEC ? 2 : 1);   // threads per block
   constexpr int LDS_LD = BK;                 // floats per LDS row: no padding, the 16-byte chunks of a row are
                                              // XOR-swizzled instead (below) so that both the staging writes and
                                              // the MFMA operand reads are bank-conflict free
   constexpr int TM = BM / WGM / 32;          // 32x32 tiles per wave along M
   constexpr int TN = BN / WGN / 32;
-  constexpr int CPR = MODE ? 4 : BK / 4;     // per-thread load units per row (MODE 0: float4; MODE 1: 8 channels)
+  constexpr int CPR = MODE ? 4 : BK / 4;     // per-thread load units per row (MODE 0: float4; MODE 1 / 2: 8 channels)
   constexpr int LDW = MODE ? 8 : 4;          // floats per load unit
-  static_assert(MODE == 0 || BK == 32, "the bf16x3 path steps K by 32 channels");
+  static_assert(MODE == 0 || BK == 32, "the bf16 paths step K by 32 channels");
   // chunk c of row r lives at chunk c ^ ((r >> SW_SHIFT) & (CPR-1)): 16 consecutive lanes of a ds_write_b128
   // (16/CPR whole rows) and of a ds_read_b128 (16 rows, one logical chunk) each cover all 64 banks once
   constexpr int SW_SHIFT = (CPR == 4) ? 2 : 1;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 
   // SPEC: tid indexes a thread inside its role group (consumers 0..NT-1, loaders 0..NT-1)
   const bool is_loader = SPEC && (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) >= WGM * WGN);
-  const int tid = (SPEC && (int)threadIdx.x >= NT) ? (int)threadIdx.x - NT : (int)threadIdx.x;
+  const int tid = (SPEC && (int)threadIdx.x >= NTC) ? (int)threadIdx.x - NTC : (int)threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
   const int ld_row = tid / CPR;              // row within a pass
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       __syncthreads();
     }
 
-  } else {
+  } else if constexpr (MODE == 1) {
     // =============================================================== MODE 1: bf16x3 operands
     // LDS row (one pixel / one output channel, 32 input channels of one tap): 12 chunks of 16 B = 192 B, no padding;
     //   logical chunk (p*4 + g) = 8 bf16 of plane p (0 hi, 1 mid, 2 lo) and channel group g (channels 8g..8g+7),
@@ -654,6 +658,146 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         __syncthreads();
       }
     }
+  } else {
+    // =============================================================== MODE 2: bf16 storage (BASELINE configs[2] "bf16")
+    // Activations of the large feature maps are STORED as bf16 (AIN = 1: [pixel][C] bf16, 16-byte loads of 8 channels)
+    // or arrive as fp32 and are rounded while they are staged (AIN = 0); the weights of these layers are rounded to
+    // bf16 once at pack time ([tap][32-channel chunk][n][32 bf16], 64 B per row).  One v_mfma_f32_32x32x16_bf16 per
+    // 32x32x16 block, fp32 accumulation: a sixth of the split-operand kernel's matrix work and a third of its LDS
+    // bytes.  LDS row = 4 chunks of 16 B (8 channels each), chunk g stored at g ^ ((row >> 2) & 3): staging writes and
+    // operand reads both conflict-free.  Double-buffered LDS, two register stages.
+    constexpr int RS = 16;
+    constexpr int NBC = (BN * 4 + NT - 1) / NT;
+    float* sA2 = smem;                               // [2][BM][RS]
+    float* sB2 = smem + 2 * BM * RS;                 // [2][BN][RS]
+    unsigned b_goff[NBC];
+    int b_loff[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) {
+      const int idx = tid + j * NT;
+      const int row = idx >> 2, c = idx & 3;
+      const bool in_tile = idx < BN * 4;
+      b_goff[j] = (in_tile && n0 + row < u_Npad) ? (unsigned)((n0 + row) * 64 + c * 16) : 0x80000000u;
+      b_loff[j] = in_tile ? row * RS + ((c ^ ((row >> 2) & 3)) << 2) : -1;
+    }
+    const int u_Cin = __builtin_amdgcn_readfirstlane(P.Cin);
+    constexpr int NAR = AIN ? 1 : 2;                 // 16-byte registers per staged A unit of 8 channels
+    u32x4 ra0[NA][NAR], ra1[NA][NAR];
+    u32x4 rb0[NBC], rb1[NBC];
+    auto gload = [&](u32x4 (&ra)[NA][NAR], u32x4 (&rb)[NBC]) {
+      const int cc0 = c_kc * 32;
+      if (cc0 < s_begin || cc0 >= s_end) {
+        const int k = (cc0 >= u_se0 ? 1 : 0) + (cc0 >= u_se1 ? 1 : 0) + (cc0 >= u_se2 ? 1 : 0);
+        s_begin = __builtin_amdgcn_readfirstlane(k ? P.seg_end[k - 1] : 0);
+        s_end = __builtin_amdgcn_readfirstlane(P.seg_end[k]);
+        const unsigned long long spa = reinterpret_cast<unsigned long long>(P.seg_ptr[k]);
+        s_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)spa);
+        s_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(spa >> 32));
+        s_ld4 = __builtin_amdgcn_readfirstlane(P.seg_ld[k]) * (AIN ? 2 : 4);     // bytes per pixel
+      }
+      const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
+      const int tap_pix = c_ty * u_W + c_tx;
+      const int col4 = (cc0 - s_begin + ld_col) * (AIN ? 2 : 4);
+      const bool ch_ok = cc0 + ld_col < u_Cin;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
+        const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < NAR; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * q), 0, 0);
+      }
+      const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 64u;
+#pragma unroll
+      for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
+      ++c_tap;
+      ++c_tx;
+      const int wx = (c_tx == u_kw) ? 1 : 0;
+      c_tx = wx ? 0 : c_tx;
+      c_ty += wx;
+      const int wt = (c_tap == n_taps) ? 1 : 0;
+      c_tap = wt ? 0 : c_tap;
+      c_ty = wt ? 0 : c_ty;
+      c_kc += wt;
+    };
+    auto pk2 = [](float lo, float hi) -> unsigned {  // two fp32 -> two bf16 (round to nearest even), lo in the low half
+      const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+      return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    };
+    const int st2_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
+    auto sstore = [&](int buf, const u32x4 (&ra)[NA][NAR], const u32x4 (&rb)[NBC]) {
+      float* a = sA2 + buf * BM * RS;
+      float* b = sB2 + buf * BN * RS;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (A_FULL || ld_row + i * RPP < BM) {
+          u32x4 t;
+          if constexpr (AIN) {
+            t = ra[i][0];
+            if (sq) {                                // GDN pools x^2: square in fp32, round back to bf16
+              unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xFFFF0000u);
+                w[q] = pk2(lo * lo, hi * hi);
+              }
+              t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
+            }
+          } else {
+            float x[8] = {__uint_as_float(ra[i][0].x), __uint_as_float(ra[i][0].y), __uint_as_float(ra[i][0].z), __uint_as_float(ra[i][0].w),
+                          __uint_as_float(ra[i][NAR - 1].x), __uint_as_float(ra[i][NAR - 1].y), __uint_as_float(ra[i][NAR - 1].z), __uint_as_float(ra[i][NAR - 1].w)};
+            if (sq) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = x[e] * x[e];
+            }
+            t.x = pk2(x[0], x[1]); t.y = pk2(x[2], x[3]); t.z = pk2(x[4], x[5]); t.w = pk2(x[6], x[7]);
+          }
+          *reinterpret_cast<u32x4*>(a + (ld_row + i * RPP) * RS + st2_col) = t;
+        }
+#pragma unroll
+      for (int j = 0; j < NBC; ++j)
+        if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(b + b_loff[j]) = rb[j];
+    };
+    const int a_row2 = (wm * TM * 32 + l31) * RS;
+    const int b_row2 = (wn * TN * 32 + l31) * RS;
+    const int rsw = (l31 >> 2) & 3;
+    const int rd2[2] = {((lh ^ rsw) << 2), (((2 + lh) ^ rsw) << 2)};
+    auto compute = [&](int buf) {
+      const float* a = sA2 + buf * BM * RS + a_row2;
+      const float* b = sB2 + buf * BN * RS + b_row2;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * RS + rd2[ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * RS + rd2[ks]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    gload(ra0, rb0);
+    sstore(0, ra0, rb0);
+    if (n_chunks > 1) gload(ra1, rb1);
+    if (n_chunks > 2) gload(ra0, rb0);
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 1 < n_chunks; ch += 2) {
+      sstore(1, ra1, rb1);
+      if (ch + 3 < n_chunks) gload(ra1, rb1);
+      compute(0);
+      __syncthreads();
+      if (ch + 2 < n_chunks) sstore(0, ra0, rb0);
+      if (ch + 4 < n_chunks) gload(ra0, rb0);
+      compute(1);
+      __syncthreads();
+    }
+    if (ch < n_chunks) {
+      compute(0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  The block's C tile goes through LDS one 32-row slab per wave-row at a time
@@ -670,6 +814,16 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
                      P.Hf == P.Ho && P.Wf == P.Wo;
   const bool vec_ok = !nchw && (!ps2 || (P.Cq & 3) == 0);
   const bool out_p3 = (P.flags & VAM_CONV_OUT_BF3) != 0;     // host guarantees: split mode, vec_ok, no PS2
+  const bool out16 = (P.flags & VAM_CONV_OUT_BF16) != 0;     // bf16 NHWC output (ldo counts bf16 elements); host guarantees vec_ok
+  const bool aux16 = (P.flags & VAM_CONV_AUX_BF16) != 0;     // pre / mul / post / post2 are bf16 NHWC tensors
+  auto ld_aux = [&](const float* base, size_t off) -> float4 {   // four consecutive channels of an epilogue operand
+    if (aux16) {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+      return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                         __uint_as_float(u.y & 0xFFFF0000u));
+    }
+    return *reinterpret_cast<const float4*>(base + off);
+  };
   const int Cc = ps2 ? P.Cq : P.N;
   const size_t HfWf = (size_t)P.Hf * P.Wf;
   // output position of a tile row (the integer divisions happen once per row, not once per element): pixel index
@@ -709,21 +863,21 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
       }
       if (P.pre) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.pre + opix * P.ld_pre + cch);
+        const float4 t4 = ld_aux(P.pre, opix * P.ld_pre + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
       if (P.mul) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.mul + opix * P.ld_mul + cch);
+        const float4 t4 = ld_aux(P.mul, opix * P.ld_mul + cch);
         v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
       }
       if (P.post) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.post + opix * P.ld_post + cch);
+        const float4 t4 = ld_aux(P.post, opix * P.ld_post + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
       if (P.post2) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.post2 + opix * P.ld_post2 + cch);
+        const float4 t4 = ld_aux(P.post2, opix * P.ld_post2 + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
       if (out_p3) {
@@ -741,6 +895,11 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         *reinterpret_cast<uint2*>(o3) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
         *reinterpret_cast<uint2*>(o3 + 16) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
         *reinterpret_cast<uint2*>(o3 + 32) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+      } else if (out16) {
+        const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1], h2 = (__bf16)v[2], h3 = (__bf16)v[3];
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(P.out) + opix * P.ldo + cch) =
+            make_uint2((unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16),
+                       (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16));
       } else {
         *reinterpret_cast<float4*>(P.out + opix * P.ldo + cch) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -880,6 +1039,23 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   dst[row + (2 * 4 + g) * 8 + e] = (unsigned short)(lb >> 16);
 }
 
+// bf16 storage mode: [tap][32-channel chunk][Npad][32 bf16] = 64 B per row, each weight rounded to nearest-even bf16
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
+                                         int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  int kk = (int)(d % 32);
+  long r = d / 32;
+  int nn = (int)(r % npad);
+  r /= npad;
+  int c_chunk = (int)(r % kc32);
+  int tap = (int)(r / kc32);
+  int ty = tap / kw, tx = tap % kw;
+  const float v = pack_value(src, mode, phase, kh, kw, cin, n, nn, c_chunk * 32 + kk, ty, tx);
+  const __bf16 h = (__bf16)v;
+  dst[d] = __builtin_bit_cast(unsigned short, h);
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -920,8 +1096,9 @@ static int conv_mode() {
 
 template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
-  constexpr size_t pipe = MODE ? (size_t)((SPEC || BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
-                               : (size_t)2 * (BM + BN) * BK * sizeof(float);
+  constexpr size_t pipe = MODE == 2 ? (size_t)2 * (BM + BN) * 16 * sizeof(float)
+                          : MODE ? (size_t)((SPEC || BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
+                                 : (size_t)2 * (BM + BN) * BK * sizeof(float);
   constexpr int crows = SPEC ? BM : WGM * 32;              // rows of C staged through LDS at a time
   constexpr size_t ctile = (size_t)crows * (BN + 4) * sizeof(float) + (size_t)crows * 2 * sizeof(int);
   constexpr size_t smem = pipe > ctile ? pipe : ctile;
@@ -1002,6 +1179,24 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int
   return check_launch("pack_weights_kernel");
 }
 
+size_t vam_conv_wpack_bf16_bytes(int kh, int kw, int cin, int n) {
+  return (size_t)kh * kw * ((cin + 31) / 32) * ((n + 31) / 32 * 32) * 64;
+}
+
+int vam_pack_conv_weights_bf16(const float* src, void* dst, int mode, int phase, int kh, int kw, int cin, int n, void* stream) {
+  VAM_REQUIRE(src && dst && kh > 0 && kw > 0 && cin > 0 && n > 0, "vam_pack_conv_weights_bf16: bad arguments");
+  VAM_REQUIRE(mode >= VAM_PACK_CONV && mode <= VAM_PACK_GDN_T, "vam_pack_conv_weights_bf16: bad mode %d", mode);
+  if (mode == VAM_PACK_PS2) VAM_REQUIRE(n % 4 == 0, "PS2 pack needs N %% 4 == 0");
+  if (mode == VAM_PACK_DECONV5S2 && phase < 0) VAM_REQUIRE(n % 4 == 0 && kh == 3 && kw == 3, "merged deconv pack needs 3x3, N=4*Cout");
+  if (mode == VAM_PACK_DECONV5S2 && phase >= 0)
+    VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
+  const int npad = (n + 31) / 32 * 32, kc32 = (cin + 31) / 32;
+  const long total = (long)kh * kw * kc32 * npad * 32;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<unsigned short*>(dst), mode, phase, kh, kw, cin, n, npad, kc32, total);
+  return check_launch("pack_weights_bf16_kernel");
+}
+
 int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream) {
   VAM_REQUIRE(src && dst && n > 0, "vam_pack_bias: bad arguments");
   hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, mode, n);
@@ -1012,7 +1207,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   VAM_REQUIRE(probs && nprob >= 1 && nprob <= VAM_MAX_GROUP, "vam_conv_group: 1..%d problems", VAM_MAX_GROUP);
   GroupArgs ga;
   ga.nprob = nprob;
-  bool in_p3 = false;
+  bool in_p3 = false, w16 = false, in16 = false;
   int bk = 0;
   long max_p = 0;
   int max_n = 0;
@@ -1026,6 +1221,14 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     VAM_REQUIRE(c.wpack && c.out, "conv[%d]: null weights/output", i);
     int cin = 0;
     const bool p3_in = (c.flags & VAM_CONV_IN_BF3) != 0, p3_out = (c.flags & VAM_CONV_OUT_BF3) != 0;
+    const bool c_w16 = (c.flags & VAM_CONV_W_BF16) != 0, c_in16 = (c.flags & VAM_CONV_IN_BF16) != 0;
+    const bool c_out16 = (c.flags & VAM_CONV_OUT_BF16) != 0, c_aux16 = (c.flags & VAM_CONV_AUX_BF16) != 0;
+    if (i == 0) { w16 = c_w16; in16 = c_in16; }
+    VAM_REQUIRE(c_w16 == w16 && c_in16 == in16, "conv group mixes bf16-storage and fp32 problems");
+    VAM_REQUIRE(!c_in16 || c_w16, "conv[%d]: bf16 input needs bf16-packed weights (VAM_CONV_W_BF16)", i);
+    if (c_w16) VAM_REQUIRE(!p3_in && !p3_out, "conv[%d]: bf16 storage and bf16x3 planes do not combine", i);
+    if (c_out16) VAM_REQUIRE(!(c.flags & (VAM_CONV_PS2 | VAM_CONV_OUT_NCHW)) && c.ldo % 4 == 0 && (((uintptr_t)c.out) & 7) == 0, "conv[%d]: bf16 output needs plain NHWC placement, ldo %% 4 == 0", i);
+    if (c_aux16) VAM_REQUIRE(!(c.flags & (VAM_CONV_OUT_NCHW)) && (!(c.flags & VAM_CONV_PS2) || (c.Cq % 4) == 0), "conv[%d]: bf16 epilogue operands need the vector epilogue", i);
     if (i == 0) in_p3 = p3_in;
     VAM_REQUIRE(p3_in == in_p3, "conv group mixes fp32 and bf16x3-plane inputs");
     if (p3_in || p3_out) VAM_REQUIRE(conv_mode() == 1, "conv[%d]: bf16x3-plane tensors need the split-operand mode", i);
@@ -1033,7 +1236,10 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     if (p3_out) VAM_REQUIRE(!(c.flags & (VAM_CONV_PS2 | VAM_CONV_OUT_NCHW)) && c.N % 8 == 0 && c.ldo * 8 >= c.N, "conv[%d]: bf16x3-plane output needs plain NHWC placement, N %% 8 == 0 and ldo (groups) >= N/8", i);
     for (int s = 0; s < VAM_MAX_SEG; ++s) {
       if (s < c.n_seg) {
-        if (p3_in) {      // ld counts 8-channel groups (48 bytes each)
+        if (c_in16) {     // ld counts bf16 elements
+          VAM_REQUIRE(c.seg[s].ptr && c.seg[s].C > 0 && c.seg[s].ld >= c.seg[s].C && c.seg[s].ld % 8 == 0 && c.seg[s].C % 8 == 0, "conv[%d]: bf16 segment %d invalid", i, s);
+          VAM_REQUIRE((((uintptr_t)c.seg[s].ptr) % 16) == 0, "conv[%d]: segment %d not 16-byte aligned", i, s);
+        } else if (p3_in) {      // ld counts 8-channel groups (48 bytes each)
           VAM_REQUIRE(c.seg[s].ptr && c.seg[s].C > 0 && c.seg[s].C % 8 == 0 && c.seg[s].ld * 8 >= c.seg[s].C, "conv[%d]: bf16x3 segment %d invalid", i, s);
           VAM_REQUIRE((((uintptr_t)c.seg[s].ptr) % 16) == 0, "conv[%d]: segment %d not 16-byte aligned", i, s);
         } else {
@@ -1050,11 +1256,11 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
         p.seg_end[s] = 1 << 30;
       }
     }
-    const int mode1 = conv_mode() == 1;
+    const int mode1 = conv_mode() == 1 || c_w16;
     int pbk = mode1 ? 32 : bk_for(cin);
     VAM_REQUIRE(cin % 16 == 0, "conv[%d]: Cin %d not a multiple of 16", i, cin);
     for (int sgi = 0; sgi < c.n_seg; ++sgi)
-      VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * (p3_in ? 48.0 : 4.0) < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
+      VAM_REQUIRE((double)c.B * c.H * c.W * c.seg[sgi].ld * (p3_in ? 48.0 : (c_in16 ? 2.0 : 4.0)) < 2147000000.0, "conv[%d]: input window larger than 2 GiB (32-bit buffer offsets)", i);
     VAM_REQUIRE((double)vam_conv_wpack_floats(c.kh, c.kw, cin, c.N) * 4.0 < 2147000000.0, "conv[%d]: packed weights larger than 2 GiB", i);
     for (int s = 0; s + 1 < c.n_seg; ++s)
       VAM_REQUIRE(p.seg_end[s] % pbk == 0, "conv[%d]: segment boundary %d not a multiple of BK=%d", i, p.seg_end[s], pbk);
@@ -1072,10 +1278,10 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       const bool vec = !(c.flags & VAM_CONV_OUT_NCHW) && (!(c.flags & VAM_CONV_PS2) || (c.Cq % 4) == 0);
       auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
       if (vec) {
-        VAM_REQUIRE((p3_out || c.ldo % 4 == 0) && al(c.out) && al(c.bias), "conv[%d]: output/bias not 16-byte aligned", i);
-        VAM_REQUIRE((!c.pre.ptr || (c.pre.ld % 4 == 0 && al(c.pre.ptr))) && (!c.mul.ptr || (c.mul.ld % 4 == 0 && al(c.mul.ptr))) &&
-                    (!c.post.ptr || (c.post.ld % 4 == 0 && al(c.post.ptr))) && (!c.post2.ptr || (c.post2.ld % 4 == 0 && al(c.post2.ptr))),
-                    "conv[%d]: epilogue operand not 16-byte aligned", i);
+        auto al8 = [](const void* q) { return (((uintptr_t)q) & 7) == 0; };
+        VAM_REQUIRE((p3_out || c.ldo % 4 == 0) && (c_out16 ? al8(c.out) : al(c.out)) && al(c.bias), "conv[%d]: output/bias not 16-byte aligned", i);
+        auto aok = [&](const vam_aux& a) { return !a.ptr || (a.ld % 4 == 0 && (c_aux16 ? al8(a.ptr) : al(a.ptr))); };
+        VAM_REQUIRE(aok(c.pre) && aok(c.mul) && aok(c.post) && aok(c.post2), "conv[%d]: epilogue operand not aligned", i);
       }
     }
     if (!(c.flags & VAM_CONV_OUT_NCHW) && !p3_out) VAM_REQUIRE(c.ldo >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N), "conv[%d]: ldo %d < channels", i, c.ldo);
@@ -1117,7 +1323,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   // bf16x3 mode: nine configurations (the wave tile needs 12 operand registers per 32 rows / columns and K step), own fit
   static const Cand cands1[9] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
                                  {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}};
-  const bool m1 = conv_mode() == 1;
+  const bool m1 = conv_mode() == 1 || w16;
   const Cand* cand = m1 ? cands1 : cands;
   const int n_cand = m1 ? 9 : 14;
   const double b512 = m1 ? 1.018 : 1.04, b256 = m1 ? 1.097 : 1.10, k96 = m1 ? 1.084 : 1.1;
@@ -1152,7 +1358,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }
-  if (conv_mode() == 1) {
+  if (conv_mode() == 1 || w16) {
     // bf16x3 path: K step is always 32; configurations whose operand fragments would not fit the register file
     // (seven 32-column groups per wave) fall back to their two-tile neighbours
     bk = 32;
@@ -1171,6 +1377,16 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
+  if (w16) {          // bf16 storage mode (MODE 2): one MFMA per block, double-buffered LDS
+#define VAM_CFG2(BM_, BN_, WGM_, WGN_) \
+    if (bm == BM_ && best_bn == BN_) return in16 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 2, 1>(ga, total, s) \
+                                                 : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 2, 0>(ga, total, s);
+    VAM_CFG2(128, 32, 4, 1) VAM_CFG2(128, 64, 2, 2) VAM_CFG2(128, 96, 4, 1) VAM_CFG2(128, 128, 2, 2) VAM_CFG2(128, 192, 2, 2)
+    VAM_CFG2(64, 32, 2, 1) VAM_CFG2(64, 64, 2, 2) VAM_CFG2(64, 128, 2, 2) VAM_CFG2(64, 192, 2, 2)
+#undef VAM_CFG2
+    set_error("vam_conv_group: no bf16 kernel configuration for BM=%d BN=%d", bm, best_bn);
+    return VAM_EINVAL;
+  }
   if (conv_mode() == 1) {
     // Wave-specialised blocks where they measured faster (interleaved A/B on one box, scratch/ab_spec.sh): the small
     // tiles of the slice chain (64x32 / 64x64 / 64x128: +12...+32 %) and the large tiles of deep-K layers (128x128,

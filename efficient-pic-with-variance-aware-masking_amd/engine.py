@@ -41,12 +41,33 @@ class Plan:
         self.cur_class = 0
         self.n_events = 0
         self._side: Dict[int, "torch.cuda.Stream"] = {}
+        # bf16-storage mode (BASELINE configs[2] "bf16"): while ``act16`` is on, intermediate tensors of at least
+        # ``act16_min_hw`` positions per image are bf16 (the large feature maps of g_a / g_s); everything at latent
+        # resolution — the sigma stacks, the mask, the likelihoods — stays fp32
+        self.act16 = False
+        self.act16_min_hw = 4096        # 64 x 64 positions per image ("bf16 activations on >= 64^2 feature maps")
 
     # ---- buffers
     def buf(self, B, H, W, C, zero=False) -> View:
+        if self.act16 and not zero and H * W >= self.act16_min_hw and C % 8 == 0:
+            v16 = ops.new_view16(B, H, W, C, self.device)
+            self.keep.append(v16.buf)
+            return v16
         v = ops.new_view(B, H, W, C, self.device, zero=zero)
         self.keep.append(v.buf)
         return v
+
+    def buf32(self, B, H, W, C) -> View:
+        """fp32 whatever the storage mode (tensors the window-attention kernel reads / writes)."""
+        v = ops.new_view(B, H, W, C, self.device)
+        self.keep.append(v.buf)
+        return v
+
+    def pk(self, m, ins, out, aux=()):
+        """Packed weights of ``m`` for a problem reading ``ins`` and writing ``out``: bf16 weights as soon as one of
+        the tensors it touches is bf16-stored."""
+        any16 = any(isinstance(v, ops.View16) for v in list(ins) + [out] + [a for a in aux if a is not None])
+        return m.packed(True) if any16 else m.packed()
 
     def buf3(self, B, H, W, C) -> "ops.View3":
         """bf16x3-plane buffer for a tensor whose only consumer is another convolution."""
@@ -278,7 +299,8 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
             last = d == depth - 1
             if last and outs[k] is not None:
                 o = outs[k]
-            elif p3 and not last and Co % 8 == 0 and m.packed().ps2_cq == 0 and v0.B * Ho * Wo <= P3_MAX_PIXELS:
+            elif p3 and not last and Co % 8 == 0 and m.packed().ps2_cq == 0 and v0.B * Ho * Wo <= P3_MAX_PIXELS and \
+                    not (plan.act16 and Ho * Wo >= plan.act16_min_hw) and not isinstance(v0, ops.View16):
                 o = plan.buf3(v0.B, Ho, Wo, Co)
             else:
                 o = plan.buf(v0.B, Ho, Wo, Co)
@@ -291,7 +313,8 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
                 c_head = m.in_channels - sum(v.C for v in cur[k])
                 probs.append(ops.conv_problem(m.packed_split(c_head)[1], cur[k], o, act, pre=hd[0], **kw))
             else:
-                probs.append(ops.conv_problem(m.packed(), cur[k], o, act, **kw))
+                probs.append(ops.conv_problem(plan.pk(m, cur[k], o, [kw.get(a_) for a_ in ("pre", "mul", "post", "post2")]),
+                                              cur[k], o, act, **kw))
             nxt.append([o])
             if last:
                 res.append(o)
@@ -305,7 +328,7 @@ def lower_gdn(plan: Plan, mods: Sequence[Ly.GDN], xs: Sequence[View], outs: Sequ
     probs, res = [], []
     for m, x, o in zip(mods, xs, outs):
         o = o if o is not None else plan.buf(x.B, x.H, x.W, x.C)
-        probs.append(ops.conv_problem(m.packed(), [x], o, L.ACT_SQRT if m.inverse else L.ACT_RSQRT, mul=x,
+        probs.append(ops.conv_problem(plan.pk(m, [x], o), [x], o, L.ACT_SQRT if m.inverse else L.ACT_RSQRT, mul=x,
                                       flags=L.CONV_SQUARE_IN))
         res.append(o)
     plan.conv(probs)
@@ -320,16 +343,16 @@ def lower_residual_units(plan: Plan, mods: Sequence[Ly.ResidualUnit], xs: Sequen
 
 def lower_win_attention(plan: Plan, mods: Sequence[Ly.WinBasedAttention], xs: Sequence[View]) -> List[View]:
     """x + proj(window_attention(qkv(x)))  (layers/win_attention.py:153-207)."""
-    qkvs = [plan.buf(x.B, x.H, x.W, 3 * x.C) for x in xs]
-    plan.conv([ops.conv_problem(m.attn.qkv.packed(), [x], q) for m, x, q in zip(mods, xs, qkvs)])
-    atts = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
+    qkvs = [plan.buf32(x.B, x.H, x.W, 3 * x.C) for x in xs]                  # q, k, v and the attention output are fp32
+    plan.conv([ops.conv_problem(plan.pk(m.attn.qkv, [x], q), [x], q) for m, x, q in zip(mods, xs, qkvs)])
+    atts = [plan.buf32(x.B, x.H, x.W, x.C) for x in xs]
     for m, q, a, x in zip(mods, qkvs, atts, xs):
         tab = m.attn.relative_position_bias_table
         plan.keep.append(tab)
         plan.call(lambda q=q, a=a, tab=tab, C_=x.C, h=m.num_heads, ws=m.window_size, sh=m.shift_size:
                   ops.win_attention(q, a, tab, C_, h, ws, sh))
     outs = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
-    plan.conv([ops.conv_problem(m.attn.proj.packed(), [a], o, post=x) for m, a, o, x in zip(mods, atts, outs, xs)])
+    plan.conv([ops.conv_problem(plan.pk(m.attn.proj, [a], o, [x]), [a], o, post=x) for m, a, o, x in zip(mods, atts, outs, xs)])
     return outs
 
 
@@ -346,7 +369,7 @@ def lower_attention_blocks(plan: Plan, mods: Sequence[Ly.Win_noShift_Attention],
     res, probs = [], []
     for m, av, bv, x, o in zip(mods, a, b, xs, outs):
         o = o if o is not None else plan.buf(x.B, x.H, x.W, x.C)
-        probs.append(ops.conv_problem(m.conv_b[4].packed(), [bv], o, L.ACT_SIGMOID, mul=av, post=x))
+        probs.append(ops.conv_problem(plan.pk(m.conv_b[4], [bv], o, [av, x]), [bv], o, L.ACT_SIGMOID, mul=av, post=x))
         res.append(o)
     plan.conv(probs)
     return res
@@ -360,7 +383,8 @@ def lower_deconv(plan: Plan, mods: Sequence[Ly.ConvTranspose2d], xs: Sequence[Vi
         nchw = out_nchw[i] if out_nchw is not None else None
         if o is None and nchw is None:
             o = plan.buf(x.B, 2 * x.H, 2 * x.W, m.out_channels)
-        for pk in m.packed():
+        any16 = isinstance(x, ops.View16) or isinstance(o, ops.View16)
+        for pk in m.packed(any16):
             probs.append(ops.conv_problem(pk, [x], o, act, out_nchw=nchw))
         res.append(o)
     plan.conv(probs)

@@ -36,14 +36,20 @@ class _Packable(nn.Module):
     def _key(self):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters(recurse=False))
 
-    def packed(self):
+    def packed(self, bf16: bool = False):
+        """Kernel-layout weights; ``bf16=True``: rounded to bf16 for the bf16-storage kernel (BASELINE configs[2])."""
         key = self._key()
+        if bf16:
+            if getattr(self, "_pk16_key", None) != key:
+                object.__setattr__(self, "_pk16", self._pack(True))
+                object.__setattr__(self, "_pk16_key", key)
+            return self._pk16
         if getattr(self, "_pk_key", None) != key:
             object.__setattr__(self, "_pk", self._pack())
             object.__setattr__(self, "_pk_key", key)
         return self._pk
 
-    def _pack(self):
+    def _pack(self, bf16: bool = False):
         raise NotImplementedError
 
 
@@ -58,10 +64,10 @@ class Conv2d(_Packable):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.kaiming_normal_(self.weight)          # models/base.py:31-36
 
-    def _pack(self):
+    def _pack(self, bf16: bool = False):
         if self.in_channels == 3 and self.kernel_size == 5 and self.stride == 2:
-            return ops.pack_conv5s2_rgb(self.weight, self.bias)
-        return ops.pack_conv(self.weight, self.bias, self.stride)
+            return ops.pack_conv5s2_rgb(self.weight, self.bias, bf16)
+        return ops.pack_conv(self.weight, self.bias, self.stride, bf16)
 
     @property
     def is_rgb_s2d(self):
@@ -117,8 +123,8 @@ class ConvTranspose2d(_Packable):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.kaiming_normal_(self.weight)
 
-    def _pack(self):
-        return ops.pack_deconv(self.weight, self.bias)
+    def _pack(self, bf16: bool = False):
+        return ops.pack_deconv(self.weight, self.bias, bf16)
 
     def forward(self, x):
         from . import engine
@@ -135,8 +141,8 @@ class Linear(_Packable):
         bound = 1 / math.sqrt(in_features)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def _pack(self):
-        return ops.pack_linear(self.weight, self.bias)
+    def _pack(self, bf16: bool = False):
+        return ops.pack_linear(self.weight, self.bias, bf16)
 
 
 class _Marker(nn.Module):
@@ -225,8 +231,8 @@ class GDN(_Packable):
         self.gamma_reparam = NonNegativeParametrizer()
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
 
-    def _pack(self):
-        return ops.pack_gdn(self.beta, self.gamma)
+    def _pack(self, bf16: bool = False):
+        return ops.pack_gdn(self.beta, self.gamma, bf16)
 
     def forward(self, x):
         from . import engine

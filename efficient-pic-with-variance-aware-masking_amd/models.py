@@ -151,6 +151,10 @@ class VarianceMaskingPIC(CompressionModel):
         self._plans: Dict[tuple, "_FsqPlan"] = {}
         self._dec_plans: Dict[tuple, "_DecPlan"] = {}
         self.use_graph = True
+        # "fp32" (default; every parity claim) or "bf16": BASELINE configs[2] — the large feature maps of g_a / g_s are
+        # stored in bf16 and multiplied by bf16-rounded weights (fp32 accumulation); the entropy-parameter stacks, the
+        # variance mask and the likelihoods stay fp32.  Differences to the fp32 path are MEASURED (bench.py --dtype bf16).
+        self.storage = "fp32"
 
     # ---- reference helpers kept for the harness
     def freeze_all(self):
@@ -269,7 +273,11 @@ class VarianceMaskingPIC(CompressionModel):
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
         key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ()) + \
-            (("own_ck",) if own_ck else ()) + (("train_gs",) if train_gs else ())
+            (("own_ck",) if own_ck else ()) + (("train_gs",) if train_gs else ()) + \
+            (("bf16",) if getattr(self, "storage", "fp32") == "bf16" else ())
+        if getattr(self, "storage", "fp32") == "bf16" and (train or symbols):
+            raise NotImplementedError("bf16 storage is an inference configuration (forward_single_quality): training and "
+                                      "the bitstream path run in fp32")
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
@@ -754,10 +762,13 @@ class _FsqPlan:
                                   "vam_s2d_input"))
         y = self.y = plan.buf(B, h, w, 2 * d)
         plan.set_class("g_a")
+        act16 = getattr(m, "storage", "fp32") == "bf16"
+        plan.act16 = act16
         if m.multiple_encoder:
             E.lower_g_a(plan, [m.g_a[0], m.g_a[1]], x_s2d, [y.window(0, d), y.window(d, d)])
         else:                                            # one encoder with M output channels (builder.py:56-67)
             E.lower_g_a(plan, [m.g_a], x_s2d, [y])
+        plan.act16 = False
 
         # ---- hyperprior                                                            pic.py:278-298
         z = plan.buf(B, h // 4, w // 4, m.N)
@@ -831,7 +842,9 @@ class _FsqPlan:
                 if train_gs:
                     self._lower_g_s_train(plan, m.g_s[0] if m.multiple_decoder else m.g_s, yb)
                 else:
+                    plan.act16 = act16
                     E.lower_g_s(plan, [m.g_s[0] if m.multiple_decoder else m.g_s], [yb], [self.x_hat])
+                    plan.act16 = False
             return
 
         # ---- progressive slices                                                    pic.py:577-643
@@ -954,7 +967,9 @@ class _FsqPlan:
             if train_gs:
                 self._lower_g_s_train(plan, g_s, yp)
             else:
+                plan.act16 = act16
                 E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
+                plan.act16 = False
 
     def _lower_g_s_train(self, plan, dec, y_in):
         """refine_gs: taped synthesis transform + its backward plan (gs_train.py)."""

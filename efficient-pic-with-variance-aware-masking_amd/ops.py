@@ -81,6 +81,40 @@ class View3:
         return (planes[..., 0, :] + planes[..., 1, :] + planes[..., 2, :]).reshape(B, H, W, self.C)
 
 
+@dataclass
+class View16:
+    """A channel window of a bf16 NHWC tensor (bf16-storage mode, BASELINE configs[2]): activations of the large feature
+    maps of g_a / g_s are kept in bf16; ``ld`` counts bf16 elements."""
+    buf: torch.Tensor   # [B, H, W, ld] torch.bfloat16, cuda
+    c0: int
+    C: int
+
+    @property
+    def B(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3]
+    @property
+    def ptr(self): return self.buf.data_ptr() + 2 * self.c0
+    @property
+    def n_pix(self): return self.B * self.H * self.W
+
+    def window(self, c0: int, C_: int) -> "View16":
+        assert c0 % 8 == 0 and C_ % 8 == 0 and 0 <= c0 and c0 + C_ <= self.C
+        return View16(self.buf, self.c0 + c0, C_)
+
+    def torch_nchw(self) -> torch.Tensor:
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2).float()
+
+
+def new_view16(B: int, H: int, W: int, C_: int, device="cuda") -> View16:
+    assert C_ % 8 == 0
+    return View16(torch.empty((B, H, W, C_), dtype=torch.bfloat16, device=device), 0, C_)
+
+
 def new_view3(B: int, H: int, W: int, C_: int, device="cuda") -> View3:
     assert C_ % 8 == 0
     return View3(torch.zeros((B, H, W, (C_ // 8) * 12), dtype=torch.float32, device=device), 0, C_)
@@ -134,12 +168,18 @@ class Packed:
     osx: int = 1
     ooy: int = 0
     oox: int = 0
+    w16: bool = False        # weights rounded to bf16 (vam_pack_conv_weights_bf16): the bf16-storage kernel
 
 
-def pack_weights(src: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int) -> torch.Tensor:
+def pack_weights(src: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int, bf16: bool = False) -> torch.Tensor:
     lib = L.load()
     src = src.detach().to(dtype=torch.float32).contiguous()
     assert src.is_cuda
+    if bf16:
+        dst = torch.empty(lib.vam_conv_wpack_bf16_bytes(kh, kw, cin, n) // 4, dtype=torch.float32, device=src.device)
+        L.check(lib.vam_pack_conv_weights_bf16(src.data_ptr(), dst.data_ptr(), mode, phase, kh, kw, cin, n, stream_ptr()),
+                "vam_pack_conv_weights_bf16")
+        return dst
     dst = torch.empty(lib.vam_conv_wpack_floats(kh, kw, cin, n), dtype=torch.float32, device=src.device)
     L.check(lib.vam_pack_conv_weights(src.data_ptr(), dst.data_ptr(), mode, phase, kh, kw, cin, n, stream_ptr()),
             "vam_pack_conv_weights")
@@ -166,18 +206,18 @@ def pack_bias(src: torch.Tensor, mode: int, n: int) -> torch.Tensor:
     return dst
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1) -> Packed:
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, bf16: bool = False) -> Packed:
     """nn.Conv2d(k, stride, padding=k//2)  (reference layers/layers.py:5-12,24-26,77-79)."""
     n, cin, kh, kw = weight.shape
-    return Packed(pack_weights(weight, L.PACK_CONV, 0, kh, kw, cin, n),
+    return Packed(pack_weights(weight, L.PACK_CONV, 0, kh, kw, cin, n, bf16),
                   None if bias is None else pack_bias(bias, L.PACK_CONV, n),
-                  kh, kw, cin, n, stride, kh // 2, kw // 2)
+                  kh, kw, cin, n, stride, kh // 2, kw // 2, w16=bf16)
 
 
-def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], bf16: bool = False) -> Packed:
     n, cin = weight.shape
-    return Packed(pack_weights(weight, L.PACK_CONV, 0, 1, 1, cin, n),
-                  None if bias is None else pack_bias(bias, L.PACK_CONV, n), 1, 1, cin, n)
+    return Packed(pack_weights(weight, L.PACK_CONV, 0, 1, 1, cin, n, bf16),
+                  None if bias is None else pack_bias(bias, L.PACK_CONV, n), 1, 1, cin, n, w16=bf16)
 
 
 def pack_subpel(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
@@ -187,7 +227,7 @@ def pack_subpel(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
                   kh, kw, cin, n, 1, kh // 2, kw // 2, ps2_cq=n // 4)
 
 
-def pack_conv5s2_rgb(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
+def pack_conv5s2_rgb(weight: torch.Tensor, bias: torch.Tensor, bf16: bool = False) -> Packed:
     """conv5x5 s2 pad2 on 3 input channels as a 3x3 s1 problem over the space-to-depth
     input of vam_s2d_input (16 channels = (py,px,c) + 4 zeros).  Pure re-indexing of the
     weights (a gather of existing values and zeros): w'[n,(py,px,c),ty,tx] = w[n,c,2ty+py,2tx+px]."""
@@ -198,11 +238,11 @@ def pack_conv5s2_rgb(weight: torch.Tensor, bias: torch.Tensor) -> Packed:
     w = w6.reshape(n, 3, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 12, 3, 3)   # [n,(py,px,c),ty,tx]
     w16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=weight.device)
     w16[:, :12] = w
-    return Packed(pack_weights(w16, L.PACK_CONV, 0, 3, 3, 16, n), pack_bias(bias, L.PACK_CONV, n),
-                  3, 3, 16, n, 1, 1, 1)
+    return Packed(pack_weights(w16, L.PACK_CONV, 0, 3, 3, 16, n, bf16), pack_bias(bias, L.PACK_CONV, n),
+                  3, 3, 16, n, 1, 1, 1, w16=bf16)
 
 
-def pack_deconv(weight: torch.Tensor, bias: torch.Tensor) -> List[Packed]:
+def pack_deconv(weight: torch.Tensor, bias: torch.Tensor, bf16: bool = False) -> List[Packed]:
     """ConvTranspose2d(k5,s2,p2,op1) (layers/layers.py:14-22) as sub-pixel phase problems.
     Cout % 4 == 0: four problems (taps 3x3,3x2,2x3,2x2) writing interleaved output pixels.
     Otherwise (Cout = 3): one merged 3x3 problem with phase-major channels + PS2 scatter."""
@@ -214,18 +254,18 @@ def pack_deconv(weight: torch.Tensor, bias: torch.Tensor) -> List[Packed]:
         for ph in range(4):
             py, px = ph >> 1, ph & 1
             k_h, k_w = (2 if py else 3), (2 if px else 3)
-            out.append(Packed(pack_weights(weight, L.PACK_DECONV5S2, ph, k_h, k_w, cin, cout), b, k_h, k_w, cin, cout,
-                              1, 0 if py else 1, 0 if px else 1, osy=2, osx=2, ooy=py, oox=px))
+            out.append(Packed(pack_weights(weight, L.PACK_DECONV5S2, ph, k_h, k_w, cin, cout, bf16), b, k_h, k_w, cin, cout,
+                              1, 0 if py else 1, 0 if px else 1, osy=2, osx=2, ooy=py, oox=px, w16=bf16))
         return out
     n = 4 * cout
-    return [Packed(pack_weights(weight, L.PACK_DECONV5S2, -1, 3, 3, cin, n), pack_bias(bias, L.PACK_DECONV5S2, n),
-                   3, 3, cin, n, 1, 1, 1, ps2_cq=cout)]
+    return [Packed(pack_weights(weight, L.PACK_DECONV5S2, -1, 3, 3, cin, n, bf16), pack_bias(bias, L.PACK_DECONV5S2, n),
+                   3, 3, cin, n, 1, 1, 1, ps2_cq=cout, w16=bf16)]
 
 
-def pack_gdn(beta: torch.Tensor, gamma: torch.Tensor) -> Packed:
+def pack_gdn(beta: torch.Tensor, gamma: torch.Tensor, bf16: bool = False) -> Packed:
     """GDN norm pool as a 1x1 problem on x^2 with the reparametrised gamma/beta (layers/gdn.py:62-69)."""
     c = beta.shape[0]
-    return Packed(pack_weights(gamma, L.PACK_GDN, 0, 1, 1, c, c), pack_bias(beta, L.PACK_GDN, c), 1, 1, c, c)
+    return Packed(pack_weights(gamma, L.PACK_GDN, 0, 1, 1, c, c, bf16), pack_bias(beta, L.PACK_GDN, c), 1, 1, c, c, w16=bf16)
 
 
 # --------------------------------------------------------------------------- conv problems
@@ -245,11 +285,20 @@ def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT
     assert 1 <= len(inputs) <= L.VAM_MAX_SEG
     in3 = isinstance(inputs[0], View3)
     assert all(isinstance(v, View3) == in3 for v in inputs), "a conv problem reads either fp32 or bf16x3-plane segments"
+    in16 = isinstance(inputs[0], View16)
+    assert all(isinstance(v, View16) == in16 for v in inputs), "a conv problem reads either fp32 or bf16 segments"
     if in3:
         flags |= L.CONV_IN_BF3
     if isinstance(out, View3):
         assert out_nchw is None
         flags |= L.CONV_OUT_BF3
+    auxs = [a for a in (pre, mul, post, post2) if a is not None]
+    aux16 = bool(auxs) and isinstance(auxs[0], View16)
+    assert all(isinstance(a, View16) == aux16 for a in auxs), "epilogue operands of one problem share a storage type"
+    if in16 or isinstance(out, View16) or aux16 or pk.w16:
+        assert pk.w16, "bf16-stored tensors are read / written by the bf16-weight kernel: pack the layer with bf16=True"
+        flags |= L.CONV_W_BF16 | (L.CONV_IN_BF16 if in16 else 0) | (L.CONV_OUT_BF16 if isinstance(out, View16) else 0) | \
+            (L.CONV_AUX_BF16 if aux16 else 0)
     B, H, W = inputs[0].B, inputs[0].H, inputs[0].W
     cin = 0
     for i, v in enumerate(inputs):

@@ -60,8 +60,14 @@ enum vam_conv_flags {
   VAM_CONV_IN_BF3 = 8,      /* every input segment holds bf16x3 planes ("P3": [pixel][8-channel group][plane 3][8 bf16],
                                48 bytes per group; seg.ld counts GROUPS per pixel, seg.C channels) written by a launch
                                with VAM_CONV_OUT_BF3 — the split-operand kernel then stages them by plain copies     */
-  VAM_CONV_OUT_BF3 = 16     /* write the result as P3 planes (ldo counts groups per pixel) instead of fp32 NHWC; for
+  VAM_CONV_OUT_BF3 = 16,    /* write the result as P3 planes (ldo counts groups per pixel) instead of fp32 NHWC; for
                                tensors whose only consumer is another convolution (inside conv stacks)               */
+  /* bf16-storage mode (BASELINE configs[2] "bf16": activations of the large feature maps stored as bf16, fp32
+   * accumulation; never used by the fp32 configurations) */
+  VAM_CONV_W_BF16 = 32,     /* wpack comes from vam_pack_conv_weights_bf16: bf16 x bf16 products, one MFMA per block    */
+  VAM_CONV_IN_BF16 = 64,    /* every input segment is a bf16 NHWC tensor (seg.ld counts bf16 elements, multiple of 8)   */
+  VAM_CONV_OUT_BF16 = 128,  /* store the result as bf16 NHWC (ldo counts bf16 elements)                                 */
+  VAM_CONV_AUX_BF16 = 256   /* pre / mul / post / post2 are bf16 NHWC tensors (their ld counts bf16 elements)           */
 };
 
 #define VAM_MAX_SEG 4
@@ -130,6 +136,10 @@ enum vam_pack_mode {
 /* Device-side repack of a weight tensor into the kernel's [tap][k-chunk][n][k] layout. */
 int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase,
                           int kh, int kw, int cin, int n, void* stream);
+/* bf16-storage mode: weights rounded to nearest-even bf16, [tap][32-channel chunk][N up to 32][32 bf16]. */
+size_t vam_conv_wpack_bf16_bytes(int kh, int kw, int cin, int n);
+int vam_pack_conv_weights_bf16(const float* src, void* dst, int mode, int phase, int kh, int kw, int cin, int n,
+                               void* stream);
 /* bias helpers: PS2 permutation / GDN beta reparam (max(b, sqrt(1e-6+2^-36))^2 - 2^-36) /
  * merged-deconv replication (4x). mode as above. */
 int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);

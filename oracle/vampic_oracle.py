@@ -198,6 +198,39 @@ def eb_forward(sd: SD, z: Tensor, prefix: str = "entropy_bottleneck."):
 # --------------------------------------------------------------------------
 # layers  (layers/layers.py, layers/gdn.py, layers/win_attention.py, layers/rem.py)
 # --------------------------------------------------------------------------
+# ---- bf16-storage emulation (BASELINE configs[2] "bf16"; the HIP path's ``model.storage = "bf16"``): tensors of at
+# least _BF16_MIN_HW positions per image inside g_a / g_s are rounded to bf16 when they are stored, and a layer that
+# reads or writes such a tensor multiplies bf16-rounded inputs by bf16-rounded weights with fp32 accumulation.  None
+# (default) = the fp32 reference path, which is what every parity claim refers to.
+_BF16_MIN_HW: Optional[int] = None
+
+
+class bf16_storage:
+    def __init__(self, min_hw: int = 4096):
+        self.min_hw = min_hw
+
+    def __enter__(self):
+        global _BF16_MIN_HW
+        self._old, _BF16_MIN_HW = _BF16_MIN_HW, self.min_hw
+
+    def __exit__(self, *a):
+        global _BF16_MIN_HW
+        _BF16_MIN_HW = self._old
+
+
+def _q(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _big(h: int, w: int) -> bool:
+    return _BF16_MIN_HW is not None and h * w >= _BF16_MIN_HW
+
+
+def _st(t: Tensor) -> Tensor:
+    """Store rounding of an intermediate feature map."""
+    return _q(t) if _big(t.shape[-2], t.shape[-1]) else t
+
+
 def nonneg(p: Tensor, minimum: float) -> Tensor:
     """compressai NonNegativeParametrizer.forward."""
     pedestal = torch.tensor([(2.0 ** -18) ** 2], dtype=torch.float32)
@@ -210,13 +243,19 @@ def gdn(sd: SD, pre: str, x: Tensor, inverse: bool) -> Tensor:
     C = x.shape[1]
     beta = nonneg(sd[pre + "beta"], 1e-6)
     gamma = nonneg(sd[pre + "gamma"], 0.0).reshape(C, C, 1, 1)
-    norm = F.conv2d(x ** 2, gamma, beta)
+    if _big(x.shape[-2], x.shape[-1]):
+        norm = F.conv2d(_q(x ** 2), _q(gamma), beta)
+    else:
+        norm = F.conv2d(x ** 2, gamma, beta)
     norm = torch.sqrt(norm) if inverse else torch.rsqrt(norm)
-    return x * norm
+    return _st(x * norm)
 
 
 def conv_k(sd: SD, pre: str, x: Tensor, stride: int = 1) -> Tensor:
     w = sd[pre + "weight"]
+    H, W = x.shape[-2:]
+    if _big(H, W) or _big(-(-H // stride), -(-W // stride)):
+        x, w = _q(x), _q(w)
     return F.conv2d(x, w, sd[pre + "bias"], stride=stride, padding=w.shape[-1] // 2)
 
 
@@ -224,15 +263,17 @@ def deconv_k(sd: SD, pre: str, x: Tensor) -> Tensor:
     """layers/layers.py:14-22 (k5 s2 pad2 outpad1)."""
     w = sd[pre + "weight"]
     k = w.shape[-1]
+    if _big(2 * x.shape[-2], 2 * x.shape[-1]):
+        x, w = _q(x), _q(w)
     return F.conv_transpose2d(x, w, sd[pre + "bias"], stride=2, padding=k // 2, output_padding=1)
 
 
 def residual_unit(sd: SD, pre: str, x: Tensor) -> Tensor:
     """layers/layers.py:30-48."""
-    o = F.gelu(conv_k(sd, pre + "conv.0.", x))
-    o = F.gelu(conv_k(sd, pre + "conv.2.", o))
+    o = _st(F.gelu(conv_k(sd, pre + "conv.0.", x)))
+    o = _st(F.gelu(conv_k(sd, pre + "conv.2.", o)))
     o = conv_k(sd, pre + "conv.4.", o)
-    return F.gelu(o + x)
+    return _st(F.gelu(o + x))
 
 
 def _rel_pos_index(ws: int) -> Tensor:
@@ -266,7 +307,9 @@ def win_attention(sd: SD, pre: str, x: Tensor, ws: int, shift: int) -> Tensor:
         t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
     win = t.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
     Bw, N, _ = win.shape
-    qkv = F.linear(win, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"])
+    big = _big(H, W)                                   # bf16-storage emulation: x is bf16-stored, q/k/v and the attention output fp32
+    qkv = F.linear(_q(win) if big else win, _q(sd[pre + "attn.qkv.weight"]) if big else sd[pre + "attn.qkv.weight"],
+                   sd[pre + "attn.qkv.bias"])
     qkv = qkv.reshape(Bw, N, 3, NUM_HEADS, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
     attn = q @ k.transpose(-2, -1)
@@ -279,11 +322,12 @@ def win_attention(sd: SD, pre: str, x: Tensor, ws: int, shift: int) -> Tensor:
         attn = attn.reshape(-1, NUM_HEADS, N, N)
     attn = torch.softmax(attn, dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
-    o = F.linear(o, sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"])
+    o = F.linear(_q(o) if big else o, _q(sd[pre + "attn.proj.weight"]) if big else sd[pre + "attn.proj.weight"],
+                 sd[pre + "attn.proj.bias"])
     o = o.reshape(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
     if shift > 0:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-    return x + o.permute(0, 3, 1, 2)
+    return _st(x + o.permute(0, 3, 1, 2))
 
 
 def attention_block(sd: SD, pre: str, x: Tensor, ws: int) -> Tensor:
@@ -296,27 +340,27 @@ def attention_block(sd: SD, pre: str, x: Tensor, ws: int) -> Tensor:
         b = residual_unit(sd, f"{pre}conv_b.{i}.", b)
     b = conv_k(sd, pre + "conv_b.4.", b)
     out = a * torch.sigmoid(b)
-    return out + x
+    return _st(out + x)
 
 
 def g_a(sd: SD, pre: str, x: Tensor) -> Tensor:
     """models/builder.py:43-53."""
-    x = gdn(sd, pre + "1.", conv_k(sd, pre + "0.", x, 2), False)
-    x = gdn(sd, pre + "3.", conv_k(sd, pre + "2.", x, 2), False)
+    x = gdn(sd, pre + "1.", _st(conv_k(sd, pre + "0.", x, 2)), False)
+    x = gdn(sd, pre + "3.", _st(conv_k(sd, pre + "2.", x, 2)), False)
     x = attention_block(sd, pre + "4.", x, 8)
-    x = gdn(sd, pre + "6.", conv_k(sd, pre + "5.", x, 2), False)
-    x = conv_k(sd, pre + "7.", x, 2)
+    x = gdn(sd, pre + "6.", _st(conv_k(sd, pre + "5.", x, 2)), False)
+    x = _st(conv_k(sd, pre + "7.", x, 2))
     return attention_block(sd, pre + "8.", x, 4)
 
 
 def g_s(sd: SD, pre: str, y: Tensor) -> Tensor:
     """models/builder.py:8-18."""
     y = attention_block(sd, pre + "0.", y, 4)
-    y = gdn(sd, pre + "2.", deconv_k(sd, pre + "1.", y), True)
-    y = gdn(sd, pre + "4.", deconv_k(sd, pre + "3.", y), True)
+    y = gdn(sd, pre + "2.", _st(deconv_k(sd, pre + "1.", y)), True)
+    y = gdn(sd, pre + "4.", _st(deconv_k(sd, pre + "3.", y)), True)
     y = attention_block(sd, pre + "5.", y, 8)
-    y = gdn(sd, pre + "7.", deconv_k(sd, pre + "6.", y), True)
-    return deconv_k(sd, pre + "8.", y)
+    y = gdn(sd, pre + "7.", _st(deconv_k(sd, pre + "6.", y)), True)
+    return deconv_k(sd, pre + "8.", y)                 # x_hat leaves in fp32
 
 
 def h_a(sd: SD, y: Tensor) -> Tensor:
