@@ -451,20 +451,12 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
         const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
 #pragma unroll
-#if defined(VAM_DIAG) && (VAM_DIAG & 16)
-        for (int q = 0; q < NAR; ++q) { ra[i][q].x = off + q; ra[i][q].y = 0x3f803f80u; ra[i][q].z = 0x3c003c00u; ra[i][q].w = 0x38003800u; }
-#else
         for (int q = 0; q < NAR; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * q), 0, 0);
-#endif
       }
       // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
       const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 192u;
 #pragma unroll
-#if defined(VAM_DIAG) && (VAM_DIAG & 8)
-      for (int j = 0; j < NBC; ++j) { rb[j].x = wbase + j; rb[j].y = 0x3f803f80u; rb[j].z = 0x3c003c00u; rb[j].w = 0x38003800u; }
-#else
       for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
-#endif
       // canonical K order: 32-channel group OUTER, tap INNER
       ++c_tap;
       ++c_tx;
@@ -484,10 +476,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         if (A_FULL || ld_row + i * RPP < BM) {
-#if defined(VAM_DIAG) && (VAM_DIAG & 2)
-          asm volatile("" :: "v"(ra[i][0]), "v"(ra[i][1]), "v"(ra[i][NAR - 1]));
-          continue;
-#endif
           if constexpr (AIN) {                       // planes arrive ready-made: three straight copies
             float* dst = a + (ld_row + i * RPP) * RS + st1_col;
             *reinterpret_cast<u32x4*>(dst) = ra[i][0];
@@ -530,11 +518,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         }
 #pragma unroll
       for (int j = 0; j < NBC; ++j) {
-#if defined(VAM_DIAG) && (VAM_DIAG & 1)
-        asm volatile("" :: "v"(rb[j]));
-#else
         if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(b + b_loff[j]) = rb[j];
-#endif
       }
     };
     const int a_row1 = (wm * TM * 32 + l31) * RS;
@@ -559,10 +543,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-#if defined(VAM_DIAG) && (VAM_DIAG & 4)
-            asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1]), "v"(fa[i][2]), "v"(fb[j][0]), "v"(fb[j][1]), "v"(fb[j][2]));
-            continue;
-#endif
             // fixed order, smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);

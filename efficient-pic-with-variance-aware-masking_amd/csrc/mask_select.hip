@@ -161,11 +161,6 @@ __global__ __launch_bounds__(1024) void variance_mask_kernel(const MaskArgs a) {
   const float d = hi_v - lo_v;
   float thr = (a.w < 0.5f) ? __builtin_fmaf(a.w, d, lo_v) : __builtin_fmaf(a.w - 1.0f, d, hi_v);
   if (sh_nan) thr = __uint_as_float(0x7FC00000u);
-#ifdef VAM_MASK_DEBUG
-  if (tid == 0 && a.thr) { a.thr[seg * 4] = thr; a.thr[seg * 4 + 1] = lo_v; a.thr[seg * 4 + 2] = hi_v; a.thr[seg * 4 + 3] = a.w; }
-#else
-  if (tid == 0 && a.thr) a.thr[seg] = thr;
-#endif
 
   if (MAXV > 0) {
 #pragma unroll

@@ -1,5 +1,8 @@
 #!/bin/bash
-# one box: the product library and every ablation build, interleaved twice
+# one box: the product library and every ablation build, interleaved twice.  The ablation builds came from temporary
+# `#if defined(VAM_DIAG) && (VAM_DIAG & bit)` switches in csrc/conv_igemm.hip (bit 1: skip the B ds_write, 2: the A ds_write,
+# 4: the MFMAs, 8: the B global loads, 16: the A global loads); they were removed again after the measurement
+# (git history: commit "bf16-storage configuration" still carries them).
 cd /root/repo
 for r in 1 2; do
   timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/diag_base_$r.log 2>&1
