@@ -161,6 +161,7 @@ __global__ __launch_bounds__(1024) void variance_mask_kernel(const MaskArgs a) {
   const float d = hi_v - lo_v;
   float thr = (a.w < 0.5f) ? __builtin_fmaf(a.w, d, lo_v) : __builtin_fmaf(a.w - 1.0f, d, hi_v);
   if (sh_nan) thr = __uint_as_float(0x7FC00000u);
+  if (tid == 0 && a.thr) a.thr[seg] = thr;
 
   if (MAXV > 0) {
 #pragma unroll

@@ -945,7 +945,7 @@ class _FsqPlan:
                 bw = self.bwd = E.Plan(device)
                 self.glik = bw.buf(B, h, w, d)
                 dmu, dsg = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
-                self.dmu, self.dsg, self.rem_io = dmu, dsg, rem_io     # kept for teacher-forced gradient checks
+                self.dmu, self.dsg, self.rem_io, self.rem_tape = dmu, dsg, rem_io, tape     # kept for teacher-forced gradient checks
                 flat = torch.zeros(sum(p.numel() for p in self.rem_params), **f32)
                 self.gflat, self.gviews, off = flat, [], 0
                 for p in self.rem_params:

@@ -187,8 +187,15 @@ def test_entropy_bottleneck():
     zh_ref, lik_ref = O.eb_forward({("e." + k): v for k, v in sd.items()}, z, "e.")
     zh, lik = eb.cuda()(z.cuda(), training=False)
     assert torch.equal(zh.cpu(), zh_ref), "z_hat must be bit-exact"
-    rel = ((lik.cpu() - lik_ref).abs() / lik_ref).max().item()
-    assert rel < 1e-4, f"EB likelihood rel err {rel}"
+    # The likelihood is a difference of two sigmoids of the 5-layer logit chain (entropy_models.py:373-383): its error
+    # is absolute (the fp32 oracle itself sits 1.0e-7 abs / 8e-6 rel from a float64 evaluation of the same formula on
+    # this input, smallest likelihood 7e-3).  Same 3e-7 abs bar as the Gaussian likelihood; the relative figure is
+    # printed and bounded where it means something (it was round 1's only, loose, assertion).
+    err = (lik.cpu() - lik_ref).abs()
+    rel = (err / lik_ref).max().item()
+    print(f"EB likelihood: abs err {err.max().item():.3g}, rel err {rel:.3g}, min lik {lik_ref.min().item():.3g}")
+    assert err.max().item() <= 3e-7, f"EB likelihood abs err {err.max().item()}"
+    assert rel <= 2e-5, rel                            # measured 6.6e-6 (the fp32 oracle's own: 8e-6)
 
 
 def test_errors_are_loud():
