@@ -89,6 +89,7 @@ _SIGNATURES = {
     "vam_pack_conv_weights_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_pack_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_conv_force_tile": (C.c_int, [C.c_int] * 3),
+    "vam_conv_force_epilogue": (C.c_int, [C.c_int]),
     "vam_conv_last_tile": (C.c_int, [C.c_void_p] * 3),
     "vam_conv_set_mode": (C.c_int, [C.c_int]),
     "vam_conv_get_mode": (C.c_int, []),

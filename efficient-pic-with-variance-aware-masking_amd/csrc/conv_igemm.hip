@@ -61,8 +61,11 @@ struct ConvP {
   int tiles_n;
 };
 
+constexpr int VAM_CONVI_STAGED = 1 << 30;   // internal ConvP flag: tensor extents beyond the direct epilogue's 32-bit window
+
 struct GroupArgs {
   int nprob;
+  int staged_epilogue;   // 1: every problem takes the LDS-staged epilogue (VAMPIC_EPILOGUE=staged: A/B measurements, bit-identity tests)
   int tile_start[VAM_MAX_GROUP + 1];
   ConvP p[VAM_MAX_GROUP];
 };
@@ -222,6 +225,11 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   unsigned s_lo = 0, s_hi = 0;
   const int n_taps = u_kh * u_kw;
   const int n_chunks = n_taps * u_Kc;        // Kc = K chunks of BK per tap
+  // fp32 NHWC outputs with fp32 epilogue operands leave straight from the accumulators (epilogue, "direct" path) in the
+  // one configuration where that measured faster (see there)
+  constexpr bool DIRECT_CFG = !SPEC && BM == 128 && BN == 64;
+  const bool direct_out = DIRECT_CFG && !args.staged_epilogue &&
+                          (P.flags & (VAM_CONV_OUT_NCHW | VAM_CONV_OUT_BF3 | VAM_CONV_OUT_BF16 | VAM_CONV_AUX_BF16 | VAM_CONVI_STAGED)) == 0;
   const int kc16 = u_kc16;                   // 16-channel packing chunks per tap
   if constexpr (MODE == 0) {
     // B rows: byte offset inside one [16-chunk][Npad][16] slab of the packed weights (constant per thread)
@@ -593,16 +601,18 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         }
         // the whole C tile goes to LDS (it fits in the pipeline buffers, which every wave has left behind the last
         // barrier); C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        float* sCf = smem;
+        if (!direct_out) {
+          float* sCf = smem;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              sCf[row * (BN + 4) + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
-            }
+              for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sCf[row * (BN + 4) + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+              }
+        }
       }
     } else if constexpr (NBUF == 2) {
       // one barrier per chunk; at the top of step ch: LDS[ch&1] = chunk ch, stage (ch+1)&1 = chunk ch+1 (requested two
@@ -906,6 +916,129 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       }
     }
   };
+  if constexpr (DIRECT_CFG) if (direct_out) {
+    // ---- direct path: every accumulator register of the 32x32 MFMA is two 128-byte row segments (32 consecutive
+    // channels of rows R and R+4), which the memory pipe takes at its full rate as one dword store per lane
+    // (MI355X_MICROARCH.md, "plain stores of the same shape").  No LDS round trip and no barrier (one, for the row
+    // table, when the output is a strided view): the operand loads of a 32x32 block are all issued before the first
+    // one is needed, where the staged path below waits for one bias / operand load after the other, slab by slab.
+    // Same operations in the same order per element as the staged path: bit-identical results
+    // (tests/test_gpu_ops.py::test_direct_and_staged_epilogues_are_bit_identical).
+    // Kept for the 128x64 one-role tile only, the tile of the short-K, store-bound layers (1x1 convolutions of GDN,
+    // residual units and attention, the 16-channel first layer), where it measured 6-17 % faster (scratch/ab_epi*.sh:
+    // 4x[96->192 1x1] 250 -> 208 us, 2x[192->192 1x1 @128] 667 -> 596 us).  Elsewhere it measured no better or worse:
+    // equal on deep-K one-role tiles, 11 % slower on the 4x1-wave 128x96 tile with 384-byte rows, and 8-22 % slower in
+    // wave-specialised blocks, whose loader waves share the staged epilogue's work but hold no accumulators.
+    int* sRow = reinterpret_cast<int*>(smem);
+    if (!dense) {
+      if ((int)threadIdx.x < BM) {
+        const int p = m0 + (int)threadIdx.x;
+        int pix = p;
+        if (p < P.P) {
+          const int ob = p / P.HoWo;
+          const int rr = p - ob * P.HoWo;
+          const int oy = rr / P.Wo;
+          const int ox = rr - oy * P.Wo;
+          if (ps2) pix = (ob * P.Hf + 2 * oy) * P.Wf + 2 * ox;
+          else pix = (ob * P.Hf + oy * P.osy + P.ooy) * P.Wf + ox * P.osx + P.oox;
+        }
+        sRow[threadIdx.x] = pix;
+      }
+      __syncthreads();
+    }
+    if (is_loader) return;
+    // 32-bit byte offsets against wave-uniform descriptors (the host sends tensors beyond the 2^31-byte window, or with
+    // 2^22 pixels or more, down the staged path): one v_mad_u32_u24 per element and operand, and rows / columns
+    // outside the problem are dropped by the hardware range check instead of branches
+    auto desc = [&](const void* q) {
+      const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+      return __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)), 0, 0x7FFFFFFF, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t r_out = desc(P.out), r_pre = desc(P.pre), r_mul = desc(P.mul), r_post = desc(P.post),
+                                 r_post2 = desc(P.post2);
+    const unsigned u_ldo = (unsigned)__builtin_amdgcn_readfirstlane(P.ldo), u_ldpre = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_pre);
+    const unsigned u_ldmul = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_mul), u_ldpost = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post);
+    const unsigned u_ldpost2 = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post2);
+    const int u_act = __builtin_amdgcn_readfirstlane(P.act);
+    const bool full_rows = m0 + BM <= P.P;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = wm * TM * 32 + i * 32 + 4 * lh;
+      unsigned pix4[16];                     // 4 x output pixel index of the 16 rows this lane holds of block row i
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int4 px = make_int4(0, 0, 0, 0);
+        if (!dense) px = *reinterpret_cast<const int4*>(sRow + row0 + 8 * g);
+        const int pxs[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = m0 + row0 + 8 * g + k;
+          pix4[g * 4 + k] = (full_rows || p < P.P) ? (unsigned)(dense ? p : pxs[k]) << 2 : 0xFFFFFFFFu;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n < P.N) {
+          unsigned cch = (unsigned)n, poff = 0;
+          if (ps2) {
+            const unsigned ph = cch / (unsigned)P.Cq;
+            cch -= ph * (unsigned)P.Cq;
+            poff = (ph >> 1) * (unsigned)P.Wf + (ph & 1);
+          }
+          // byte offset of element (row r, this lane's channel) of an operand with row pitch ld
+          auto off = [&](int r, unsigned ld, unsigned c4) -> int {
+            const unsigned o = __umul24(pix4[r], ld) + c4;
+            return (int)((full_rows || pix4[r] != 0xFFFFFFFFu) ? o : 0x80000000u);
+          };
+          float v[16], t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+          if (P.bias) {
+            const float bv = P.bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += bv;
+          }
+          if (P.pre) {
+            const unsigned c4 = (poff * u_ldpre + cch) << 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_pre, off(r, u_ldpre, c4), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], u_act);
+          if (P.mul) {
+            const unsigned c4 = (poff * u_ldmul + cch) << 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_mul, off(r, u_ldmul, c4), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= t[r];
+          }
+          if (P.post) {
+            const unsigned c4 = (poff * u_ldpost + cch) << 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_post, off(r, u_ldpost, c4), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t[r];
+          }
+          if (P.post2) {
+            const unsigned c4 = (poff * u_ldpost2 + cch) << 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_post2, off(r, u_ldpost2, c4), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t[r];
+          }
+          const unsigned c4o = (poff * u_ldo + cch) << 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (SPEC) {
     if ((int)threadIdx.x < BM) decode_row((int)threadIdx.x, (int)threadIdx.x);
     __syncthreads();                         // the consumers' C tile and the row table are in LDS
@@ -1060,6 +1193,7 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restric
 }
 
 static int g_force[3] = {0, 0, 0};   // tuning hook: forced BM / BN / BK (0 = automatic)
+static int g_staged = -1;             // tuning / test hook: 1 = staged epilogue everywhere, 0 = automatic, -1 = VAMPIC_EPILOGUE
 static int g_last[3] = {0, 0, 0};   // tile configuration of the most recent launch (diagnostics)
 
 static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
@@ -1112,6 +1246,11 @@ int vam_conv_last_tile(int* bm, int* bn, int* bk) {
 
 int vam_conv_force_tile(int bm, int bn, int bk) {
   g_force[0] = bm; g_force[1] = bn; g_force[2] = bk;
+  return VAM_OK;
+}
+
+int vam_conv_force_epilogue(int staged) {
+  g_staged = staged < 0 ? -1 : (staged ? 1 : 0);
   return VAM_OK;
 }
 
@@ -1187,6 +1326,14 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   VAM_REQUIRE(probs && nprob >= 1 && nprob <= VAM_MAX_GROUP, "vam_conv_group: 1..%d problems", VAM_MAX_GROUP);
   GroupArgs ga;
   ga.nprob = nprob;
+  {
+    static int staged_env = -1;
+    if (staged_env < 0) {
+      const char* e = getenv("VAMPIC_EPILOGUE");
+      staged_env = (e && e[0] == 's') ? 1 : 0;
+    }
+    ga.staged_epilogue = g_staged >= 0 ? g_staged : staged_env;
+  }
   bool in_p3 = false, w16 = false, in16 = false;
   int bk = 0;
   long max_p = 0;
@@ -1277,6 +1424,19 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
     p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
     p.Cq = c.Cq; p.act = c.act; p.flags = c.flags;
+    {
+      // the kernel addresses every input segment with 32-bit byte offsets inside a 2^31-byte window
+      const double in_pix = (double)c.B * c.H * c.W;
+      for (int s = 0; s < c.n_seg; ++s)
+        VAM_REQUIRE(in_pix * c.seg[s].ld * (p3_in ? 48.0 : c_in16 ? 2.0 : 4.0) < 2147483648.0, "conv[%d]: input segment %d spans 2 GiB or more (split the batch)", i, s);
+      // the direct epilogue does the same for the output and the epilogue operands, with 24-bit pixel arithmetic;
+      // anything larger takes the staged epilogue (64-bit addresses)
+      const double out_pix = (double)c.B * c.Hf * c.Wf;
+      auto fits = [&](const void* q, int ld) { return !q || (ld < (1 << 24) && out_pix * ld * 4.0 < 2147483648.0); };
+      if (!(out_pix < (double)(1 << 22) && fits(c.out, c.ldo) && fits(c.pre.ptr, c.pre.ld) && fits(c.mul.ptr, c.mul.ld) &&
+            fits(c.post.ptr, c.post.ld) && fits(c.post2.ptr, c.post2.ld)))
+        p.flags |= VAM_CONVI_STAGED;
+    }
     p.pre = c.pre.ptr; p.ld_pre = c.pre.ld;
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;

@@ -150,6 +150,11 @@ int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
 int vam_conv_group(const vam_conv* problems, int n_problems, void* stream);
 /* Tuning hook: force the tile (BM in {64,128}, BN in {32,...,224}, BK in {16,32}); 0 = automatic. */
 int vam_conv_force_tile(int bm, int bn, int bk);
+/* Test / measurement hook.  fp32 NHWC outputs normally leave the kernel straight from the accumulator registers
+ * ("direct" epilogue); 1 sends every problem through the LDS-staged epilogue instead (the one bf16 / plane / NCHW
+ * outputs always take), 0 = automatic, -1 = follow the environment variable VAMPIC_EPILOGUE=staged.  Both epilogues
+ * perform the same operations per element: results are bit-identical. */
+int vam_conv_force_epilogue(int staged);
 /* Arithmetic of the convolution kernel.  1 (default): every fp32 operand is split exactly into three bf16 terms and
  * the product is formed from six exact bf16 x bf16 partial products on the bf16 matrix pipe, fp32 accumulation
  * (error vs float64 no larger than the fp32 fma chain's); 0: fp32 operands on the fp32 matrix pipe.

@@ -1,0 +1,23 @@
+#!/bin/bash
+cd /root/repo
+export VAMPIC_SPEC=0
+for r in 1 2; do
+ for act in ACT_NONE ACT_GELU; do
+  ACT=$act timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/epi3_direct_${act}_$r.log 2>&1
+  ACT=$act VAMPIC_EPILOGUE=staged timeout -k 10 120 python scratch/diag_bench.py > gpurun_out/epi3_staged_${act}_$r.log 2>&1
+ done
+done
+python - <<'PY'
+import re
+rows = {}
+A=("ACT_NONE","ACT_GELU")
+for act in A:
+  for n in ("direct", "staged"):
+    for r in (1, 2):
+        for ln in open(f"gpurun_out/epi3_{n}_{act}_{r}.log"):
+            m = re.match(r"(.*?) tile (\S+)\s+([\d.]+) us", ln)
+            if m: rows.setdefault((m.group(1), m.group(2)), {}).setdefault((act,n), []).append(float(m.group(3)))
+print("SPEC=0  %-40s %-8s" % ("shape", "tile") + "".join("%9s" % (a[4:8]+"/"+n[:3]) for a in A for n in ("staged","direct")))
+for (s, t), d in rows.items():
+    print("%-40s %-8s" % (s, t) + "".join("%9.1f" % min(d[(a,n)]) for a in A for n in ("staged","direct")))
+PY

@@ -28,7 +28,7 @@ for npb, cin, n, k, st, B, H, W, p3 in SHAPES:
         else:
             x = ops.new_view(B, H, W, cin); x.buf.normal_()
         o = ops.new_view(B, H // st, W // st, n)
-        probs.append(ops.conv_problem(m.packed(), [x], o, L.ACT_GELU)); keep += [m, x, o]
+        probs.append(ops.conv_problem(m.packed(), [x], o, getattr(L, os.environ.get('ACT', 'ACT_GELU')))); keep += [m, x, o]
     for _ in range(3):
         ops.conv_group(probs)
     torch.cuda.synchronize()

@@ -231,6 +231,45 @@ def test_conv_result_is_independent_of_tiling():
             assert torch.equal(o, outs[0]), (cin, n, k, st)
 
 
+def test_direct_and_staged_epilogues_are_bit_identical():
+    """On the 128x64 tile fp32 NHWC outputs leave the convolution kernel straight from the accumulator registers (direct
+    epilogue); every other tile, bf16 / plane / NCHW outputs and tensors beyond its 32-bit window go through LDS
+    (staged epilogue).  Same operations per
+    element in the same order: every module must produce the same bits either way — dense outputs, the strided views
+    of the four deconvolution phases, the pixel-shuffle scatter, bias / pre / mul / post operands (GDN, residual
+    units, attention, REM), ragged channel counts and a ragged last row tile, every tile shape."""
+    from vampic.models import _hyper_synthesis
+    lib = L.load()
+    cases = []
+    m = Ly.Conv2d(176, 144, 3, 1); _fill(m, 51); cases.append(("conv ragged N", m, (_rand((3, 176, 9, 7), 52),)))
+    m = Ly.Conv2d(192, 192, 5, 2); _fill(m, 53); cases.append(("conv 5x5 s2", m, (_rand((2, 192, 32, 32), 54),)))
+    m = Ly.ConvTranspose2d(192, 192); _fill(m, 55); cases.append(("deconv phases", m, (_rand((2, 192, 8, 12), 56),)))
+    m = _hyper_synthesis(192, 192, 320); _fill(m, 57); cases.append(("subpel stack", m, (_rand((2, 192, 2, 3), 58),)))
+    m = Ly.GDN(192); _fill(m, 59); cases.append(("gdn", m, (_rand((2, 192, 16, 16), 60, 2.0),)))
+    m = Ly.GDN(192, inverse=True); _fill(m, 61); cases.append(("igdn", m, (_rand((2, 192, 16, 16), 62, 2.0),)))
+    m = Ly.Win_noShift_Attention(dim=192, num_heads=8, window_size=8, shift_size=4); _fill(m, 63)
+    cases.append(("attention block", m, (_rand((2, 192, 16, 24), 64),)))
+    m = Ly.LatentRateReduction(32, True, "middle"); _fill(m, 65)
+    att = (vampic.synth.uniform((2, 32, 8, 8), 66) > 0.5).float()
+    cases.append(("rem block", m, (_rand((2, 32, 8, 8), 67, 3.0), _rand((2, 64, 8, 8), 68), _rand((2, 64, 8, 8), 69), torch.cat([att, att], 1))))
+    for what, m, xs in cases:
+        m = m.cuda()
+        xs = [x.cuda() for x in xs]
+        outs = []
+        for staged, tile in ((1, (0, 0)), (0, (0, 0)), (1, (128, 64)), (0, (128, 64)), (0, (64, 64)), (0, (128, 192))):
+            lib.vam_conv_force_epilogue(staged)
+            lib.vam_conv_force_tile(tile[0], tile[1], 0)
+            try:
+                with torch.no_grad():
+                    outs.append(m(*xs).clone())
+            finally:
+                lib.vam_conv_force_epilogue(-1)
+                lib.vam_conv_force_tile(0, 0, 0)
+        assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0, what
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), what
+
+
 def test_conv_accuracy_against_float64():
     """The convolution kernel against a float64 convolution of the same fp32 inputs.  The default kernel splits every
     fp32 operand exactly into three bf16 terms and sums six exact partial products in fp32, so
