@@ -123,12 +123,28 @@ def uniform(shape, seed: int) -> torch.Tensor:
     return _uniform(tuple(shape), _gen("uniform:" + "x".join(map(str, shape)), seed))
 
 
+_MEMO = None     # (name, shape, dtype, seed) -> tensor, when memoize(True) was called (test sessions that build many models)
+
+
+def memoize(on: bool = True) -> None:
+    """Keep every synthetic tensor drawn by :func:`synth_state_dict` (values depend on name, shape and seed only, so
+    the model variants of one test session share almost all of them; the draws cost seconds per model)."""
+    global _MEMO
+    _MEMO = {} if on else None
+
+
 def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
     """Fill every entry of ``template`` (name -> tensor giving shape/dtype)."""
     out = {}
     for k, v in template.items():
+        key = (k, tuple(v.shape), v.dtype, seed)
+        if _MEMO is not None and key in _MEMO:
+            out[k] = _MEMO[key].clone()
+            continue
         t = synth_tensor(k, v, seed)
         out[k] = v.detach().clone().cpu() if t is None else t.to(v.dtype)
+        if _MEMO is not None and t is not None:
+            _MEMO[key] = out[k].clone()
     return out
 
 

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import vampic.synth
+    vampic.synth.memoize(True)      # the dozen model variants of a session share their synthetic tensors (seconds per model)
 
 
 README_ARGS = dict(N=192, M=640, multiple_decoder=True, multiple_encoder=True, multiple_hyperprior=True,
