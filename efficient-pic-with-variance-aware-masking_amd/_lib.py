@@ -23,7 +23,7 @@ CONV_W_BF16, CONV_IN_BF16, CONV_OUT_BF16, CONV_AUX_BF16 = 32, 64, 128, 256      
 PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD, PACK_GDN_T = range(6)
 # enum vam_ew_op
 (EW_GELU_FWD, EW_GELU_BWD, EW_GATE_BWD, EW_GDN_APPLY, EW_GDN_BWD_PREP, EW_GDN_BWD_FIN, EW_CLAMP_BWD, EW_AXPY, EW_GATE_FWD,
- EW_REPARAM_BWD) = range(10)
+ EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD) = range(12)
 # enum vam_family
 FAM_CONV, FAM_ATTN, FAM_MASK, FAM_TAIL, FAM_MISC = range(5)
 FAMILY_NAMES = ("conv_igemm", "win_attn", "variance_mask", "gauss_tail", "misc")

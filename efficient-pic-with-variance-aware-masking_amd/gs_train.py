@@ -295,9 +295,11 @@ def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
     return dx
 
 
-def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torch.Tensor, pk: TransformPacks, grads):
-    """dL/d(parameters of the transform) from dL/dx_hat (NCHW, ``g_xhat``); nothing upstream of the transform's input is
-    trainable in this schedule (train.py:216-218)."""
+def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torch.Tensor, pk: TransformPacks, grads,
+                       need_input_grad: bool = False) -> Optional[View]:
+    """dL/d(parameters of the transform) from dL/dx_hat (NCHW, ``g_xhat``).  Nothing upstream of the transform's input is
+    trainable under plain ``refine_gs`` (train.py:216-218); with ``--lrp`` the latent-residual-prediction stacks are
+    (models/pic.py:171-184), and ``need_input_grad`` returns dL/dy_hat for them."""
     B, _, H, W = x_hat.shape
     gcl = torch.zeros_like(x_hat)
     d16 = bw.buf(B, H, W, 16, zero=True)
@@ -313,4 +315,65 @@ def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torc
         elif r["kind"] == "gdn":
             d = _gdn_bwd(bw, pk, r, d, grads)
         else:
-            d = _attention_block_bwd(bw, pk, r, d, grads, need_dx=not first)
+            d = _attention_block_bwd(bw, pk, r, d, grads, need_dx=(not first) or need_input_grad)
+    return d
+
+
+# ============================================================================= latent-residual-prediction stacks (--lrp)
+def lower_lrp_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[Sequence[View]],
+                           rqs: Sequence[View], bases: Sequence[View], outs: Sequence[View],
+                           packs: Sequence[TransformPacks]) -> List[dict]:
+    """K progressive LRP stacks in lockstep with a tape (pic.py:635-641: y_hat_j = rq_j + 0.5 tanh(stack_j(cat(supports,
+    rq_j))) + base_j).  Same kernels as the eval lowering, but every layer writes its pre-activation and the GELU / the
+    0.5 tanh tail are element-wise launches with the epilogue's formulas.  The eval plan computes the hyperprior part of
+    the first layer ahead of the slice loop (engine.lower_stack_heads: same sum, different association); a TRAINED stack
+    runs its first layer whole, so its forward agrees with the eval plan to fp32 rounding, not bit for bit."""
+    K = len(stacks)
+    lay = [E.conv_layers(s) for s in stacks]
+    depth = len(lay[0])
+    cur: List[List[View]] = [list(i) for i in inputs]
+    tapes = [dict(stack=stacks[k], x=[], z=[]) for k in range(K)]
+    for d in range(depth):
+        zs = []
+        probs = []
+        for k in range(K):
+            m, act = lay[k][d]
+            assert isinstance(m, Ly.Conv2d) and m.stride == 1 and act == (L.ACT_NONE if d == depth - 1 else L.ACT_GELU)
+            v0 = cur[k][0]
+            z = plan.buf(v0.B, v0.H, v0.W, m.out_channels)
+            probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], z))
+            tapes[k]["x"].append(list(cur[k]))
+            tapes[k]["z"].append(z)
+            zs.append(z)
+        plan.conv(probs)
+        if d < depth - 1:
+            cur = [[_gelu(plan, z)] for z in zs]
+        else:
+            for z, rq, yb, o in zip(zs, rqs, bases, outs):
+                plan.call(lambda z=z, rq=rq, yb=yb, o=o: ops.ew(L.EW_HTANH_FWD, [z, rq, yb], [o]), "lrp tail")
+    return tapes
+
+
+def lower_lrp_stacks_backward(bw: E.Plan, tapes: Sequence[dict], d_outs: Sequence[View], packs: Sequence[TransformPacks], grads):
+    """dL/d(parameters of the LRP stacks) from dL/dy_hat_j.  The stacks' inputs (hyperprior means, supports, rq_j) have no
+    trainable producer in this schedule, so the first layer needs no data gradient."""
+    K = len(tapes)
+    lay = [E.conv_layers(t["stack"]) for t in tapes]
+    depth = len(lay[0])
+    dz = []
+    for t, dy in zip(tapes, d_outs):
+        z = t["z"][-1]
+        o = bw.buf(z.B, z.H, z.W, z.C)
+        bw.call(lambda z=z, dy=dy, o=o: ops.ew(L.EW_HTANH_BWD, [z, dy], [o]), "lrp tail bwd")
+        dz.append(o)
+    for d in range(depth - 1, -1, -1):
+        wg = []
+        for k in range(K):
+            m = lay[k][d][0]
+            wg += ops.wgrad_problems(tapes[k]["x"][d], dz[k], grads[id(m.weight)], grads[id(m.bias)])
+        bw.wgrad(wg)
+        if d == 0:
+            break
+        das = [bw.buf(t["z"][d - 1].B, t["z"][d - 1].H, t["z"][d - 1].W, t["z"][d - 1].C) for t in tapes]
+        bw.conv([ops.conv_problem(packs[k].d[id(lay[k][d][0])], [dz[k]], das[k]) for k in range(K)])
+        dz = [_gelu_bwd(bw, tapes[k]["z"][d - 1], das[k]) for k in range(K)]

@@ -12,7 +12,7 @@ models/pic.py:25-666, models/rem_pic.py:8-422.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -268,12 +268,12 @@ class VarianceMaskingPIC(CompressionModel):
             raise ValueError("support_progressive_slices must be >= 0")
 
     def _plan(self, x, base_only: bool, rem_idx: Optional[int] = None, symbols: bool = False,
-              train: bool = False, own_ck: bool = False, train_gs: bool = False) -> "_FsqPlan":
+              train: bool = False, own_ck: bool = False, train_gs: bool = False, train_lrp: bool = False) -> "_FsqPlan":
         B, C_, H, W = x.shape
         if C_ != 3 or H % 64 or W % 64:
             raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
         key = (B, H, W, base_only, rem_idx, str(x.device)) + ((True,) if symbols else ()) + (("train",) if train else ()) + \
-            (("own_ck",) if own_ck else ()) + (("train_gs",) if train_gs else ()) + \
+            (("own_ck",) if own_ck else ()) + (("train_gs",) if train_gs else ()) + (("train_lrp",) if train_lrp else ()) + \
             (("bf16",) if getattr(self, "storage", "fp32") == "bf16" else ())
         if getattr(self, "storage", "fp32") == "bf16" and (train or symbols):
             raise NotImplementedError("bf16 storage is an inference configuration (forward_single_quality): training and "
@@ -281,12 +281,13 @@ class VarianceMaskingPIC(CompressionModel):
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
-        wsig = self._weights_sig(self._decoder_in_use(base_only) if train_gs else None)
+        trained = ([self._decoder_in_use(base_only)] if train_gs else []) + ([self.lrp_transforms_prog] if train_lrp else [])
+        wsig = self._weights_sig(trained)
         if p is not None and p.wsig != wsig:
             p = None                # a parameter was edited in place (param.data.copy_, nn.init, optimizer step)
         if p is None:
             p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck,
-                         train_gs=train_gs)
+                         train_gs=train_gs, train_lrp=train_lrp)
             p.wsig = wsig
             self._plans[key] = p
         return p
@@ -294,16 +295,17 @@ class VarianceMaskingPIC(CompressionModel):
     def _decoder_in_use(self, base_only: bool):
         return (self.g_s[0 if base_only else 1] if self.multiple_decoder else self.g_s)
 
-    def _weights_sig(self, trained: Optional[nn.Module] = None):
+    def _weights_sig(self, trained: Sequence[nn.Module] = ()):
         """(_version, data_ptr) of every parameter the plans pack ONCE (everything except ``post_latent`` — and except
-        ``trained``, the transform a training plan re-packs in place every step): a plan built before an in-place edit
+        ``trained``, the modules a training plan re-packs in place every step): a plan built before an in-place edit
         of a weight must not be replayed."""
         cache = self.__dict__.setdefault("_sig_params", {})
-        ps = cache.get(id(trained))
+        key = tuple(id(t) for t in trained)
+        ps = cache.get(key)
         if ps is None:
-            skip = {id(p) for p in trained.parameters()} if trained is not None else set()
+            skip = {id(p) for t in trained for p in t.parameters()}
             ps = [p for n, p in self.named_parameters() if not n.startswith("post_latent.") and id(p) not in skip]
-            cache[id(trained)] = ps
+            cache[key] = ps
         h = 0
         for p in ps:
             h = (h * 1000003 + p._version * 31 + (p.data_ptr() >> 4)) & 0xFFFFFFFFFFFFFFF
@@ -318,17 +320,24 @@ class VarianceMaskingPIC(CompressionModel):
         are STE-rounded, so every other output equals the eval pass) — VALUES only: the transforms outside the REMs have
         no backward kernels in this build, so asking for their gradients fails loudly instead of silently
         returning none.  ``noise`` = {"y": NCHW, "z": NCHW} injects fixed draws."""
-        train_gs = False
+        train_gs = train_lrp = False
         if training and torch.is_grad_enabled() and self._trainable_outside_rem():
-            # `--training_type refine_gs` (train.py:150-157,216-218): only the synthesis transform in use trains
+            # `--training_type refine_gs` (train.py:150-157,216-218): the synthesis transform in use trains, with `--lrp`
+            # (unfreeze_decoder(lrp=True), pic.py:171-184) the progressive latent-residual-prediction stacks as well
             dec_ids = {id(p) for p in self._decoder_in_use(quality == 0).parameters()}
+            lrp_ps = list(self.lrp_transforms_prog.parameters())
+            lrp_ids = {id(p) for p in lrp_ps}
             other = [n for n, p in self.named_parameters()
-                     if p.requires_grad and not n.startswith("post_latent.") and id(p) not in dec_ids]
-            if other or not self.all_scalable:
-                raise NotImplementedError("backward kernels exist for the synthesis transform (refine_gs: freeze_all(); "
-                                          "unfreeze_decoder()) and the REMs; gradients of g_a / hyperprior / slice stacks "
-                                          f"(SURVEY K14) are not built yet — trainable outside: {other[:3]}")
-            train_gs = True
+                     if p.requires_grad and not n.startswith("post_latent.") and id(p) not in dec_ids and id(p) not in lrp_ids]
+            n_lrp = sum(p.requires_grad for p in lrp_ps)
+            if other or not self.all_scalable or (n_lrp and (quality == 0 or n_lrp != len(lrp_ps))):
+                raise NotImplementedError("backward kernels exist for the synthesis transform and the progressive LRP stacks "
+                                          "(refine_gs: freeze_all(); unfreeze_decoder(lrp=...)) and for the REMs; gradients "
+                                          "of g_a / hyperprior / entropy-parameter stacks (SURVEY K14) are not built yet — "
+                                          f"trainable outside: {other[:3]}")
+            if not any(p.requires_grad for p in self._decoder_in_use(quality == 0).parameters()):
+                raise NotImplementedError("LRP stacks trainable without the synthesis transform: not a schedule of the reference")
+            train_gs, train_lrp = True, bool(n_lrp)
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
             raise NotImplementedError()
@@ -345,7 +354,7 @@ class VarianceMaskingPIC(CompressionModel):
                                  for i in range(0, x.shape[0], nb)])
         if train_gs and x.shape[0] > nb:
             raise NotImplementedError("refine_gs training: batch larger than one plan's 32-bit addressing range")
-        plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training), train_gs=train_gs)
+        plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training), train_gs=train_gs, train_lrp=train_lrp)
         out = plan.execute(x.detach(), pr, None, self.use_graph, clone, noise=noise)
         if train_gs:
             out["x_hat"] = _GsTrainFn.apply(plan, out["x_hat"], self.use_graph, *plan.gs_params)
@@ -732,9 +741,10 @@ class _FsqPlan:
     """``forward_single_quality`` for one (B,H,W) lowered to libvampic launches."""
 
     def __init__(self, m: VarianceMaskingPIC, B, H, W, base_only, rem_idx, device, symbols=False, train=False,
-                 own_ck=False, train_gs=False):
+                 own_ck=False, train_gs=False, train_lrp=False):
         self.m, self.B, self.H, self.W = m, B, H, W
         self.train_gs = train_gs    # the synthesis transform in use is being trained (refine_gs): taped g_s + backward plan
+        self.train_lrp = train_lrp  # ... and the progressive LRP stacks with it (refine_gs --lrp)
         self.own_ck, self.ck_pr = own_ck, 0.0     # fine-tune: derive the checkpoint latent inside this plan
         self.base_only, self.rem_idx = base_only, rem_idx
         self.symbols = symbols
@@ -959,23 +969,37 @@ class _FsqPlan:
                                      rem_io[3], self.packs, grads)
         if indexes:                                                                   # pic.py:813
             plan.call(lambda: ops.build_indexes(std_f, table, mask=self.mask, out=self.idx.window(d, d)))
-        E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
-                       [sl(yp, j) for j in range(ns)],
-                       [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
+        lrp = None
+        if train_lrp:
+            from . import gs_train as G
+            stacks = [m.lrp_transforms_prog[j] for j in range(ns)]
+            lpk = [G.TransformPacks(st) for st in stacks]
+            for pk_ in lpk:
+                pk_.record_refresh(plan)
+            mh1 = means_h.window(d, d)
+            tapes = G.lower_lrp_stacks_train(plan, stacks, [[mh1] + msups[j] + [sl(rq, j)] for j in range(ns)],
+                                             [sl(rq, j) for j in range(ns)], [sl(yb, j) for j in range(ns)],
+                                             [sl(yp, j) for j in range(ns)], lpk)
+            lrp = dict(tapes=tapes, packs=lpk, params=[p for st in stacks for p in st.parameters()])
+        else:
+            E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)], [msups[j] + [sl(rq, j)] for j in range(ns)],
+                           [sl(yp, j) for j in range(ns)],
+                           [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)   # :635-641
         if not symbols:
             plan.set_class("g_s")
             if train_gs:
-                self._lower_g_s_train(plan, g_s, yp)
+                self._lower_g_s_train(plan, g_s, yp, lrp)
             else:
                 plan.act16 = act16
                 E.lower_g_s(plan, [g_s], [yp], [self.x_hat])
                 plan.act16 = False
 
-    def _lower_g_s_train(self, plan, dec, y_in):
-        """refine_gs: taped synthesis transform + its backward plan (gs_train.py)."""
+    def _lower_g_s_train(self, plan, dec, y_in, lrp=None):
+        """refine_gs: taped synthesis transform + its backward plan (gs_train.py); ``lrp`` = the taped progressive LRP
+        stacks when they train too (refine_gs --lrp): their gradients come from dL/dy_hat, the input gradient of g_s."""
         from . import gs_train as G
         dev = self.x_in.device
-        self.gs_params = list(dec.parameters())
+        self.gs_params = list(dec.parameters()) + (lrp["params"] if lrp else [])
         self.gs_packs = G.TransformPacks(dec)
         self.gs_packs.record_refresh(plan)
         tape = G.lower_g_s_train(plan, dec, y_in, self.x_hat, self.gs_packs)
@@ -989,7 +1013,11 @@ class _FsqPlan:
         self.gs_views = [self.gs_flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.gs_params)]
         grads = {id(p): g for p, g in zip(self.gs_params, self.gs_views)}
         bw.keep += [self.g_xhat, self.gs_flat, self.gs_views]
-        G.lower_g_s_backward(bw, tape, self.x_hat, self.g_xhat, self.gs_packs, grads)
+        d_y = G.lower_g_s_backward(bw, tape, self.x_hat, self.g_xhat, self.gs_packs, grads, need_input_grad=lrp is not None)
+        if lrp is not None:
+            self.lrp_tapes, self.d_yhat = lrp["tapes"], d_y                    # kept for teacher-forced gradient checks
+            G.lower_lrp_stacks_backward(bw, lrp["tapes"], [d_y.window(32 * j, 32) for j in range(len(lrp["tapes"]))],
+                                        lrp["packs"], grads)
 
     def backward_gs(self, grad_x_hat: torch.Tensor, use_graph: bool):
         """dL/d(parameters of the trained synthesis transform) for dL/dx_hat; fresh tensors in ``gs_params`` order."""

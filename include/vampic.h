@@ -306,7 +306,9 @@ enum vam_ew_op {
   VAM_EW_CLAMP_BWD = 6,     /* in0 = clamp_(v,0,1), in1 = dL/dout: out0 = dL/dv                      (pic.py:558,651) */
   VAM_EW_AXPY = 7,          /* out0 = in0 + coef * in1                                                                 */
   VAM_EW_GATE_FWD = 8,      /* in0 = a, in1 = b, in2 = x: out0 = a*sigmoid(b) + x                                      */
-  VAM_EW_REPARAM_BWD = 9    /* NonNegativeParametrizer backward: in0 = stored parameter, in1 = dL/dvalue, coef = bound */
+  VAM_EW_REPARAM_BWD = 9,   /* NonNegativeParametrizer backward: in0 = stored parameter, in1 = dL/dvalue, coef = bound */
+  VAM_EW_HTANH_FWD = 10,    /* LRP tail (pic.py:635-641): in0 = z, in1 = quantised residual, in2 = base: (0.5 tanh z + in1) + in2 */
+  VAM_EW_HTANH_BWD = 11     /* in0 = z, in1 = dy: out0 = dy * 0.5 (1 - tanh(z)^2)                                         */
 };
 typedef struct vam_ew {
   vam_aux in[4];

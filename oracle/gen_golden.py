@@ -27,7 +27,7 @@ sys.dont_write_bytecode = True
 
 import vampic.synth as synth  # noqa: E402  (pure python/torch, no GPU needed)
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("VAMPIC_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden"))     # (another directory: regenerate without touching the committed files)
 Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
 
 
@@ -301,6 +301,33 @@ def main():
     others = [k for k, p_ in pic.named_parameters() if p_.grad is not None and not k.startswith("g_s.1.")]
     assert not others, others
     np.savez_compressed(os.path.join(GOLD, "refine_gs_step.npz"), **rec)
+
+    # 8c. the same step with `--lrp` (train.py:216-218 -> unfreeze_decoder(lrp=True), pic.py:171-184): the ten progressive
+    #     latent-residual-prediction stacks train with g_s[1].
+    pic.zero_grad(set_to_none=True)
+    pic.freeze_all()
+    pic.unfreeze_decoder(lrp=True)
+    torch.manual_seed(1)
+    o = pic.forward_single_quality(xr, quality=2.5, training=True)
+    crit = loss_mod2.DistortionLoss(device="cpu")(o, xr)
+    crit["loss"].backward()
+    rec = {"loss": np.array([crit["loss"].item(), crit["mse_loss"].item()], dtype=np.float64),
+           "x_hat": o["x_hat"].detach()[:, :, ::4, ::4].numpy()}
+    names, norms, samples = [], [], []
+    for k, p_ in pic.named_parameters():
+        if p_.grad is None:
+            continue
+        assert k.startswith("g_s.1.") or k.startswith("lrp_transforms_prog."), k
+        gflat = p_.grad.detach().reshape(-1)
+        names.append(k)
+        norms.append(gflat.double().norm().item())
+        samples.append(gflat[::389].numpy())
+    assert sum(n.startswith("lrp_transforms_prog.") for n in names) == 100, len(names)
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms, dtype=np.float64)
+    rec["grad_samples"] = np.concatenate(samples).astype(np.float32)      # every 389th element of each gradient
+    np.savez_compressed(os.path.join(GOLD, "refine_gs_lrp_step.npz"), **rec)
+    pic.zero_grad(set_to_none=True)
     pic.eval()
 
     # 9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each

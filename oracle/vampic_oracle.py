@@ -687,16 +687,38 @@ def rem_training_step(sd: SD, x: Tensor, quality: float, checkpoint_ref: Tensor,
 #      synthesis transform of the progressive decoder; DistortionLoss (training/loss.py:126-187)
 # --------------------------------------------------------------------------
 def refine_gs_training_step(sd: SD, x: Tensor, quality: float, *, lmbda: float = 1e-2, weight: float = 255.0 ** 2,
-                            prefix: str = "g_s.1.", **flags):
+                            prefix: str = "g_s.1.", lrp: bool = False, **flags):
     """One ``refine_gs`` step: the frozen front end gives y_hat (its STE-rounded values equal the eval pass, pic.py:629),
     x_hat = g_s[1](y_hat).clamp(0, 1), loss = weight * lmbda * mean((x - x_hat)^2).  Returns (loss, mse, x_hat,
-    {name: gradient}) for the parameters under ``prefix``."""
-    y_hat = forward_single_quality(sd, x, quality, **flags)["y_hat"].detach()
-    leaves = {k: (v.clone().requires_grad_(True) if k.startswith(prefix) and v.dtype.is_floating_point else v)
+    {name: gradient}) for the parameters under ``prefix`` — and, with ``lrp`` (``unfreeze_decoder(lrp=True)``,
+    pic.py:171-184), under ``lrp_transforms_prog.``: y_hat_j = rq_j + 0.5 tanh(lrp_j(cat(mean support, rq_j))) + y_base_j
+    (pic.py:629-641) is then recomputed under autograd from the front end's (frozen) tensors; README flags only."""
+    ref = forward_single_quality(sd, x, quality, **flags)
+    trained = (prefix,) + (("lrp_transforms_prog.",) if lrp else ())
+    leaves = {k: (v.clone().requires_grad_(True) if k.startswith(trained) and v.dtype.is_floating_point else v)
               for k, v in sd.items()}
+    if lrp:
+        assert not flags, "the LRP recomputation follows the README configuration"
+        div, chunk, sp = 320, 32, 5
+        y, yb, mu, mask = ref["y"], ref["y_base"], ref["mu"], ref["mask"]
+        means_h = compute_hyperprior(sd, y, quality)[0]
+        mu_tot = mu + yb                                                  # pic.py:601
+        sl = lambda t, j, n=1: t[:, j * chunk:(j + n) * chunk]
+        parts = []
+        for j in range(div // chunk):
+            s = min(sp, j)
+            msup = torch.cat([means_h[:, div:], sl(yb, j)] + ([sl(mu_tot, j - s, s)] if s else []), 1)
+            r = sl(y, div // chunk + j) - sl(y, j)
+            rh = torch.round(r - sl(mu, j)) * sl(mask, j) + sl(mu, j)
+            parts.append(rh + 0.5 * torch.tanh(cc_stack(leaves, f"lrp_transforms_prog.{j}.", torch.cat([msup, rh], 1))) + sl(yb, j))
+        y_hat = torch.cat(parts, 1)
+        assert torch.equal(y_hat.detach(), ref["y_hat"]), "LRP recomputation must reproduce the forward pass"
+    else:
+        y_hat = ref["y_hat"].detach()
     x_hat = g_s(leaves, prefix, y_hat).clamp(0, 1)
     mse = F.mse_loss(x, x_hat)
     loss = weight * (lmbda * mse)
     loss.backward()
-    grads = {k[len(prefix):]: v.grad for k, v in leaves.items() if k.startswith(prefix) and torch.is_tensor(v) and v.grad is not None}
+    grads = {(k[len(prefix):] if k.startswith(prefix) else k): v.grad for k, v in leaves.items()
+             if k.startswith(trained) and torch.is_tensor(v) and v.grad is not None}
     return loss.detach(), mse.detach(), x_hat.detach(), grads

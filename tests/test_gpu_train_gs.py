@@ -230,3 +230,103 @@ def test_refine_gs_teacher_forced_and_loop(pic_model):
     m.unfreeze_encoder()                                          # anything outside the decoder still fails loudly
     with pytest.raises(NotImplementedError):
         m.forward_single_quality(x, quality=1.5, training=True)
+
+
+def _train_plan(m, B, H, W):
+    return [p for k, p in m._plans.items() if "train_lrp" in k and k[:3] == (B, H, W)][0]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_refine_gs_lrp_step_matches_reference_gradients(pic_model, use_graph):
+    """`refine_gs --lrp` (train.py:216-218 -> unfreeze_decoder(lrp=True), pic.py:171-184): g_s[1] and the ten progressive
+    latent-residual-prediction stacks train.  One step against the REFERENCE's own run (tests/golden/refine_gs_lrp_step.npz:
+    100 + 100 gradient tensors): loss 1e-5 relative, every gradient norm within 2e-3, all sampled entries jointly 5e-4."""
+    net0, sd = pic_model
+    m = copy.deepcopy(net0).train()
+    m.use_graph = use_graph
+    m.freeze_all()
+    m.unfreeze_decoder(lrp=True)
+    gold = np.load(os.path.join(GOLD, "refine_gs_lrp_step.npz"))
+    x = synth.synth_image(1, 64, 64, seed=3).cuda()
+    for rep in range(2):                                          # the second pass replays the captured graphs
+        m.zero_grad(set_to_none=True)
+        out = m.forward_single_quality(x, quality=2.5, training=True)
+        loss = _distortion_loss(out, x)
+        loss.backward()
+        assert abs(float(loss.detach()) - gold["loss"][0]) <= 1e-5 * gold["loss"][0], (float(loss), gold["loss"][0])
+        assert np.abs(out["x_hat"].detach().cpu()[:, :, ::4, ::4].numpy() - gold["x_hat"]).max() <= 1e-4
+        params = dict(m.named_parameters())
+        err = {"g_s.1.": [0.0, 0.0], "lrp_transforms_prog.": [0.0, 0.0]}
+        off = 0
+        for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+            name = str(name)
+            g = params[name].grad.reshape(-1).cpu()
+            s_ = g[::389].numpy()
+            ref = gold["grad_samples"][off:off + len(s_)]
+            off += len(s_)
+            assert abs(float(g.double().norm()) - norm) <= 2e-3 * norm + 1e-12, (name, float(g.double().norm()), norm)
+            e = err["g_s.1." if name.startswith("g_s.1.") else "lrp_transforms_prog."]
+            e[0] += float(((s_ - ref).astype(np.float64) ** 2).sum())
+            e[1] += float((ref.astype(np.float64) ** 2).sum())
+        print("refine_gs --lrp gradients, joint relative error:", {k: f"{(v[0] / v[1]) ** 0.5:.2e}" for k, v in err.items()})
+        assert all((v[0] / v[1]) ** 0.5 <= 5e-4 for v in err.values())
+        trained = ("g_s.1.", "lrp_transforms_prog.")
+        assert all((p.grad is not None) == n.startswith(trained) for n, p in m.named_parameters())
+
+
+def test_refine_gs_lrp_teacher_forced_and_loop(pic_model):
+    """(a) the LRP stacks' gradients against autograd over the ORACLE's cc_stack fed the plan's own stack inputs and its
+    own dL/dy_hat (teacher-forced: 5e-5 of each tensor's max); the taped forward agrees with the eval plan to fp32
+    rounding (a trained stack runs its first layer whole, the eval plan splits off the hyperprior part);
+    (b) an Adam loop over both parameter groups lowers the distortion, leaves everything else bit-identical, and the
+    eval plan sees the new LRP weights."""
+    net0, sd = pic_model
+    m = copy.deepcopy(net0).train()
+    m.freeze_all()
+    m.unfreeze_decoder(lrp=True)
+    B, H, W = 2, 64, 128
+    x = synth.synth_image(B, H, W, seed=5).cuda()
+    with torch.no_grad():
+        ev = m.forward_single_quality(x, 1.5)
+    out = m.forward_single_quality(x, quality=1.5, training=True)
+    assert (out["y_hat"] - ev["y_hat"]).abs().max().item() <= 2e-5 and (out["x_hat"].detach() - ev["x_hat"]).abs().max().item() <= 1e-4
+    loss = _distortion_loss(out, x)
+    loss.backward()
+    plan = _train_plan(m, B, H, W)
+    nchw = lambda v: v.torch_nchw().detach().cpu().clone()
+    for j in (0, 3, 9):
+        tape = plan.lrp_tapes[j]
+        inp = torch.cat([nchw(v) for v in tape["x"][0]], 1)
+        pre = f"lrp_transforms_prog.{j}."
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+        res = 0.5 * torch.tanh(O.cc_stack(leaves, pre, inp))
+        res.backward(nchw(plan.d_yhat.window(32 * j, 32)))
+        for n, p in m.lrp_transforms_prog[j].named_parameters():
+            assert _rel(p.grad, leaves[pre + n].grad) <= 5e-5, (j, n, _rel(p.grad, leaves[pre + n].grad))
+    trained = ("g_s.1.", "lrp_transforms_prog.")
+    frozen = {n: p.detach().clone() for n, p in m.named_parameters() if not n.startswith(trained)}
+    lrp_before = m.lrp_transforms_prog[4][0].weight.detach().clone()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        o = m.forward_single_quality(x, quality=1.5, training=True)
+        ls = _distortion_loss(o, x)
+        ls.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(ls.detach()))
+    print("refine_gs --lrp losses:", [round(v, 3) for v in losses])
+    assert losses[-1] < losses[0]
+    assert not torch.equal(lrp_before, m.lrp_transforms_prog[4][0].weight)
+    with torch.no_grad():
+        after = m.forward_single_quality(x, 1.5)
+    assert not torch.equal(after["y_hat"], ev["y_hat"])            # the eval plan was rebuilt on the new LRP weights
+    for n, p in m.named_parameters():
+        if not n.startswith(trained):
+            assert torch.equal(p, frozen[n]), n
+    # an LRP subset, or the LRP stacks at quality 0 (base decoder), is not a schedule of the reference: loud
+    for p in m.lrp_transforms_prog[3].parameters():
+        p.requires_grad = False
+    with pytest.raises(NotImplementedError):
+        m.forward_single_quality(x, quality=1.5, training=True)

@@ -265,3 +265,31 @@ def test_oracle_refine_gs_step_matches_reference():
         off += len(s_)
         assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
         assert np.abs(s_ - ref).max() <= 1e-5 * norm + 1e-12, name
+
+
+def test_oracle_refine_gs_lrp_step_matches_reference():
+    """`--training_type refine_gs --lrp` (unfreeze_decoder(lrp=True), pic.py:171-184): the oracle's step — y_hat recomputed
+    under autograd through the ten progressive LRP stacks — against the reference's own run
+    (tests/golden/refine_gs_lrp_step.npz: 100 g_s[1] + 100 LRP gradients)."""
+    import argparse
+    import vampic
+    from conftest import README_ARGS
+    net = vampic.get_model(argparse.Namespace(model="pic", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    gold = np.load(os.path.join(GOLD, "refine_gs_lrp_step.npz"))
+    x = synth.synth_image(1, 64, 64, seed=3)
+    loss, mse, x_hat, grads = O.refine_gs_training_step(sd, x, 2.5, lrp=True)
+    assert abs(float(loss) - gold["loss"][0]) <= 1e-6 * gold["loss"][0] and abs(float(mse) - gold["loss"][1]) <= 1e-6 * gold["loss"][1]
+    _close(x_hat[:, :, ::4, ::4], gold["x_hat"], 2e-5)
+    names = [str(n) for n in gold["grad_names"]]
+    key = lambda n: n[len("g_s.1."):] if n.startswith("g_s.1.") else n          # the oracle strips its decoder prefix
+    assert sorted(grads) == sorted(key(n) for n in names)
+    assert sum(n.startswith("lrp_transforms_prog.") for n in names) == 100
+    off = 0
+    for name, norm in zip(names, gold["grad_norms"]):
+        g = grads[key(name)].reshape(-1)
+        s_ = g[::389].numpy()
+        ref = gold["grad_samples"][off:off + len(s_)]
+        off += len(s_)
+        assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
+        assert np.abs(s_ - ref).max() <= 1e-5 * norm + 1e-12, name
