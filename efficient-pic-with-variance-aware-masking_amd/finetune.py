@@ -1,5 +1,7 @@
-"""REM fine-tune driver (BASELINE configs[4]; reference train.py:167-184,223-226 and
-training/step.py:14-95 with ``--training_type rems``; loss training/loss.py:189-229).
+"""Fine-tune drivers: REM fine-tune (BASELINE configs[4]; reference train.py:167-184,223-226 and
+training/step.py:14-95 with ``--training_type rems``; loss training/loss.py:189-229) and decoder refinement
+(``--training_type refine_gs`` [``--lrp``]: train.py:150-157,216-218, training/step.py:56-99, loss training/loss.py:126-187;
+at the end of this file).
 
 Only the Rate-Enhancement blocks train; every step is
     checkpoint latent at the check level (no grad)  ->  training-mode forward at a sampled quality
@@ -115,6 +117,87 @@ def train_one_epoch(model, criterion, train_dataloader: Iterable[torch.Tensor], 
         red_dev = device if (_dist_backend() == "nccl") else "cpu"
         q = list_quality[sharding.broadcast_choice(len(list_quality), rng, red_dev)]
         crit = finetune_step(model, criterion, d, optimizer, q, rems, clip_max_norm)
+        for k in tot:
+            tot[k] += float(crit[k].detach().mean())
+        n += 1
+        counter += 1
+    n = max(n, 1)
+    return counter, tot["loss"] / n, tot["bpp_loss"] / n, tot["mse_loss"] / n, tot["bpp_scalable"] / n
+
+
+# ============================================================================= decoder refinement (--training_type refine_gs)
+class DistortionLoss(nn.Module):
+    """training/loss.py:126-187: loss = weight * lmbda * mse(x, x_hat); the rates are reported only (and, like the
+    reference's, computed from whatever likelihoods the forward returned)."""
+
+    def __init__(self, weight=255 ** 2, device="cuda"):
+        super().__init__()
+        self.weight, self.device = weight, device
+
+    def forward(self, output, target, lmbda=1e-2):
+        n_img, _, H, W = target.size()
+        n_rec = output["x_hat"].shape[0]
+        tgt = target
+        if n_rec != 1 and n_rec != n_img:
+            tgt = target.unsqueeze(0).repeat(n_rec, 1, 1, 1, 1)
+        out = {"mse_loss": torch.nn.functional.mse_loss(tgt, output["x_hat"])}
+        den = -math.log(2) * n_img * H * W
+        lik = output["likelihoods"]
+        out["bpp_hype"] = torch.log(lik["z"].detach()).sum() / den
+        out["bpp_base"] = torch.log(lik["y"].detach().squeeze(0)).sum() / den
+        out["bpp_scalable"] = out["bpp_base"] * 0.0
+        out["bpp_loss"] = out["bpp_scalable"] + out["bpp_base"] + n_rec * out["bpp_hype"]
+        out["loss"] = self.weight * (lmbda * out["mse_loss"]).mean()
+        return out
+
+
+def refine_gs_quality_list() -> List[float]:
+    """The qualities a ``refine_gs`` epoch samples from (train.py:150-155; the same two ``np.arange`` expressions: 203 levels
+    up to 1.5, 51 from 1.6 to 10)."""
+    import numpy as np
+    a = list(np.arange(0.015, 1.5, (1.5 - 0.025) / 200)) + [1.5]
+    b = list(np.arange(1.6, 10, (10 - 1.6) / 50)) + [10]
+    return [float(q) for q in a + b]
+
+
+def refine_gs_setup(model, lrp: bool = False):
+    """train.py:216-218: ``freeze_all(); unfreeze_decoder(lrp=args.lrp)``; returns the trainable parameters."""
+    model.freeze_all()
+    model.unfreeze_decoder(lrp=lrp)
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def refine_gs_step(model, criterion, batch: torch.Tensor, optimizer, quality: float, clip_max_norm: float = 1.0,
+                   lmbda: float = 1e-2, noise=None) -> dict:
+    """One optimisation step of the decoder-refinement schedule on this rank's shard (training/step.py:56-99 with
+    ``sampling_training=True, rems=None``): training-mode forward at ``quality``, DistortionLoss, backward (HIP kernels of
+    gs_train.py), gradient all-reduce in one rank-invariant bucket, clip, optimizer step."""
+    optimizer.zero_grad()
+    out = model.forward_single_quality(batch, quality=quality, training=True, noise=noise)
+    crit = criterion(out, batch, lmbda=lmbda)
+    crit["loss"].backward()
+    sharding.all_reduce_gradients([p for p in model.parameters() if p.requires_grad])
+    if clip_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
+    optimizer.step()
+    return crit
+
+
+def train_one_epoch_refine_gs(model, criterion, train_dataloader: Iterable[torch.Tensor], optimizer, epoch: int, counter: int,
+                              list_quality: Optional[Sequence[float]] = None, clip_max_norm: float = 1.0, rng=random):
+    """``train_one_epoch(..., sampling_training=True, list_quality=..., lmbda_list=None, rems=None)`` of the reference:
+    one sampled quality per batch (drawn on rank 0 for the whole job, so that the ranks' gradients belong to the same
+    objective).  Returns (counter, mean loss, mean bpp, mean mse, mean scalable bpp)."""
+    model.train()
+    device = next(model.parameters()).device
+    list_quality = refine_gs_quality_list() if list_quality is None else list_quality
+    tot = {"loss": 0.0, "bpp_loss": 0.0, "mse_loss": 0.0, "bpp_scalable": 0.0}
+    n = 0
+    for d in train_dataloader:
+        d = d.to(device)
+        red_dev = device if (_dist_backend() == "nccl") else "cpu"
+        q = list_quality[sharding.broadcast_choice(len(list_quality), rng, red_dev)]
+        crit = refine_gs_step(model, criterion, d, optimizer, q, clip_max_norm)
         for k in tot:
             tot[k] += float(crit[k].detach().mean())
         n += 1

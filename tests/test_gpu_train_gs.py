@@ -2,6 +2,7 @@
 GPU: the backward kernels of the synthesis transform against torch autograd over the oracle, the full step against the
 gradients the REFERENCE computed (tests/golden/refine_gs_step.npz)."""
 import copy
+import math
 import os
 
 import numpy as np
@@ -330,3 +331,29 @@ def test_refine_gs_lrp_teacher_forced_and_loop(pic_model):
         p.requires_grad = False
     with pytest.raises(NotImplementedError):
         m.forward_single_quality(x, quality=1.5, training=True)
+
+
+def test_refine_gs_epoch_driver(pic_model):
+    """vampic.finetune's decoder-refinement driver (train.py:150-157,216-218 + training/step.py:56-99 with
+    sampling_training=True): setup freezes / unfreezes as the reference does, an epoch over a fixed batch samples one quality
+    per step from the reference's list, applies DistortionLoss and Adam, and the distortion at a fixed quality goes down."""
+    import random
+    from vampic import finetune as FT
+    net0, sd = pic_model
+    m = copy.deepcopy(net0)
+    params = FT.refine_gs_setup(m, lrp=True)
+    assert {n.split(".")[0] for n, p in m.named_parameters() if p.requires_grad} == {"g_s", "lrp_transforms_prog"}
+    assert all(n.startswith("g_s.1.") or n.startswith("lrp_transforms_prog.") for n, p in m.named_parameters() if p.requires_grad)
+    qs = FT.refine_gs_quality_list()
+    assert len(qs) == 254 and qs[0] == 0.015 and qs[-1] == 10.0 and all(b > a for a, b in zip(qs, qs[1:]))
+    crit = FT.DistortionLoss(device="cuda")
+    x = synth.synth_image(2, 64, 64, seed=8).cuda()
+
+    def fixed_loss():
+        with torch.no_grad():
+            return float(torch.nn.functional.mse_loss(x, m.eval().forward_single_quality(x, 2.5)["x_hat"]))
+    before = fixed_loss()
+    opt = torch.optim.Adam(params, lr=1e-4)
+    counter, loss, bpp, mse, bpp_s = FT.train_one_epoch_refine_gs(m, crit, [x] * 8, opt, epoch=0, counter=0, rng=random.Random(3))
+    assert counter == 8 and math.isfinite(loss) and loss > 0 and bpp > 0 and bpp_s == 0.0 and mse > 0
+    assert fixed_loss() < before
