@@ -559,6 +559,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
           }
+        // seven column groups per wave: 112 accumulator + 96 fragment registers; keep hipcc from hoisting the next
+        // sub-step's 96 fragment registers above this one's MFMAs (39 spilled registers otherwise)
+        if constexpr (TN >= 7) __builtin_amdgcn_sched_barrier(0);
       }
     };
     if constexpr (SPEC) {
@@ -1461,15 +1464,29 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     if (kt > ktot_max) ktot_max = kt;
   }
   // bf16x3 mode: nine configurations (the wave tile needs 12 operand registers per 32 rows / columns and K step), own fit
-  static const Cand cands1[9] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
-                                 {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}};
+  static const Cand cands1[10] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
+                                  {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}, {128, 224, 1.0}};
   const bool m1 = conv_mode() == 1 || w16;
   const Cand* cand = m1 ? cands1 : cands;
-  const int n_cand = m1 ? 9 : 14;
+  const int n_cand = m1 ? 10 : 14;
+  // deep-K launches of the split-operand mode may use the wave-specialised 128x224 tile (4x1 consumer waves of 32 x 224:
+  // the layers with 224 output channels without padding them to 256); it exists as a specialised block only
+  int min_chunks32 = 1 << 30;
+  for (int i = 0; i < nprob; ++i) {
+    const int nc = ga.p[i].kh * ga.p[i].kw * ((ga.p[i].Cin + 31) / 32);
+    if (nc < min_chunks32) min_chunks32 = nc;
+  }
+  static int spec_env0 = -2;
+  if (spec_env0 == -2) {
+    const char* e = getenv("VAMPIC_SPEC");
+    spec_env0 = e ? (e[0] == '1' ? 1 : 0) : -1;
+  }
+  const bool wide224_ok = conv_mode() == 1 && !w16 && spec_env0 != 0 && min_chunks32 >= 16;
   const double b512 = m1 ? 1.018 : 1.04, b256 = m1 ? 1.097 : 1.10, k96 = m1 ? 1.084 : 1.1;
   int bm = 128, best_bn = 128;
   double best_score = -1.0;
   for (int c = 0; c < n_cand; ++c) {
+    if (m1 && cand[c].bn == 224 && !wide224_ok) continue;
     double padded = 0.0, real = 0.0;
     long blocks = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -1503,7 +1520,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     // (seven 32-column groups per wave) fall back to their two-tile neighbours
     bk = 32;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = (ga.p[i].Cin + 31) / 32;
-    if (best_bn == 224) best_bn = 128;                 // (only reachable through vam_conv_force_tile)
+    if (best_bn == 224 && !(bm == 128 && wide224_ok)) best_bn = 128;
     if (best_bn == 160) best_bn = (bm == 128) ? 96 : 64;
     if (bm == 64 && best_bn == 96) best_bn = 64;
   }
@@ -1543,7 +1560,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       if (nc < min_chunks) min_chunks = nc;
     }
     const bool spec_tile = (bm == 64 && (best_bn == 32 || best_bn == 64 || best_bn == 128)) || (bm == 128 && (best_bn == 128 || best_bn == 192));
-    const bool spec = spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16);
+    const bool spec = (bm == 128 && best_bn == 224) || (spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16));
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
     if (bm == BM_ && best_bn == BN_) {                                                                      \
       if (spec) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 1>(ga, total, s)                  \
@@ -1554,6 +1571,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     VAM_CFG1(128, 32, 4, 1) VAM_CFG1(128, 64, 2, 2) VAM_CFG1(128, 96, 4, 1) VAM_CFG1(128, 128, 2, 2) VAM_CFG1(128, 192, 2, 2)
     VAM_CFG1(64, 32, 2, 1) VAM_CFG1(64, 64, 2, 2) VAM_CFG1(64, 128, 2, 2) VAM_CFG1(64, 192, 2, 2)
 #undef VAM_CFG1
+    if (bm == 128 && best_bn == 224)
+      return in_p3 ? launch_cfg<128, 224, 32, 4, 1, 1, 1, 1>(ga, total, s) : launch_cfg<128, 224, 32, 4, 1, 1, 0, 1>(ga, total, s);
     set_error("vam_conv_group: no bf16x3 kernel configuration for BM=%d BN=%d", bm, best_bn);
     return VAM_EINVAL;
   }

@@ -218,7 +218,7 @@ def test_conv_result_is_independent_of_tiling():
         _fill(m, 21)
         x = _rand((4, cin) + hw, 22).cuda()
         outs = []
-        for bm, bn, bk in ((0, 0, 0), (64, 64, 16), (64, 64, 32), (128, 64, 16), (128, 192, 16), (64, 128, 32), (128, 32, 16)):
+        for bm, bn, bk in ((0, 0, 0), (64, 64, 16), (64, 64, 32), (128, 64, 16), (128, 192, 16), (64, 128, 32), (128, 32, 16), (128, 224, 32)):
             if bk == 32 and cin % 32:
                 continue
             lib.vam_conv_force_tile(bm, bn, bk)
