@@ -1463,7 +1463,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     int kt = ga.p[i].Cin * ga.p[i].kh * ga.p[i].kw;
     if (kt > ktot_max) ktot_max = kt;
   }
-  // bf16x3 mode: nine configurations (the wave tile needs 12 operand registers per 32 rows / columns and K step), own fit
+  // bf16x3 mode: nine configurations (the wave tile needs 12 operand registers per 32 rows / columns and K step), own fit,
+  // plus the wave-specialised 128x224 tile (below)
   static const Cand cands1[10] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
                                   {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}, {128, 224, 1.0}};
   const bool m1 = conv_mode() == 1 || w16;
