@@ -74,7 +74,6 @@ class VamConv(C.Structure):
         ("act", C.c_int32),
         ("flags", C.c_int32),
         ("pre", VamAux), ("mul", VamAux), ("post", VamAux), ("post2", VamAux),
-        ("gdn_w", C.c_void_p), ("gdn_b", C.c_void_p), ("gdn_inverse", C.c_int32),
     ]
 
 

@@ -59,9 +59,6 @@ struct ConvP {
   const float* post2;
   int ld_pre, ld_mul, ld_post, ld_post2;
   int tiles_n;
-  const float* gdn_w;   // fused GDN / IGDN behind this convolution (128x192 wave-specialised tile): packed gamma' planes,
-  const float* gdn_b;   // beta', and 1 for the inverse form
-  int gdn_inv;
 };
 
 constexpr int VAM_CONVI_STAGED = 1 << 30;   // internal ConvP flag: tensor extents beyond the direct epilogue's 32-bit window
@@ -231,7 +228,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   // fp32 NHWC outputs with fp32 epilogue operands leave straight from the accumulators (epilogue, "direct" path) in the
   // one configuration where that measured faster (see there)
   constexpr bool DIRECT_CFG = !SPEC && BM == 128 && BN == 64;
-  constexpr bool GDN_CFG = SPEC && MODE == 1 && AIN == 0 && BM == 128 && BN == 192;   // the configuration that can carry a fused GDN
   const bool direct_out = DIRECT_CFG && !args.staged_epilogue &&
                           (P.flags & (VAM_CONV_OUT_NCHW | VAM_CONV_OUT_BF3 | VAM_CONV_OUT_BF16 | VAM_CONV_AUX_BF16 | VAM_CONVI_STAGED)) == 0;
   const int kc16 = u_kc16;                   // 16-channel packing chunks per tap
@@ -482,34 +478,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     };
     static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
     const int st1_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
-    // eight fp32 channels of one row -> the three bf16 planes of their (swizzled) LDS chunk.  Exact 3-way split by
-    // truncation: hi = top 16 bits of x, mid = top 16 bits of (x - hi), lo = x - hi - mid (at most 8 significant bits
-    // are left, so its top 16 bits hold it exactly); two AND + two SUB per element and one byte-permute per plane and
-    // element pair.  dst = swizzled chunk of plane 0; planes are 16 floats apart
-    auto split_store = [&](float* dst, const float (&x)[8]) {
-      unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        hb[e] = __float_as_uint(x[e]);
-        const float r1 = x[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
-        mb[e] = __float_as_uint(r1);
-        lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e] & 0xFFFF0000u));
-      }
-      unsigned hw[4], mw[4], lw[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        hw[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);   // {hi16(odd), hi16(even)}
-        mw[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
-        lw[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
-      }
-      u32x4 t;
-      t.x = hw[0]; t.y = hw[1]; t.z = hw[2]; t.w = hw[3];
-      *reinterpret_cast<u32x4*>(dst) = t;
-      t.x = mw[0]; t.y = mw[1]; t.z = mw[2]; t.w = mw[3];
-      *reinterpret_cast<u32x4*>(dst + 16) = t;
-      t.x = lw[0]; t.y = lw[1]; t.z = lw[2]; t.w = lw[3];
-      *reinterpret_cast<u32x4*>(dst + 32) = t;
-    };
     auto sstore = [&](int buf, const u32x4 (&ra)[NA][NAR], const u32x4 (&rb)[NBC]) {
       float* a = sA1 + buf * BM * RS;
       float* b = sB1 + buf * BN * RS;
@@ -529,7 +497,32 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = x[e] * x[e];
           }
-          split_store(a + (ld_row + i * RPP) * RS + st1_col, x);
+          // exact 3-way split by truncation: hi = top 16 bits of x, mid = top 16 bits of (x - hi), lo = x - hi - mid
+          // (at most 8 significant bits are left, so its top 16 bits hold it exactly); two AND + two SUB per element
+          // and one byte-permute per plane and element pair
+          unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            hb[e] = __float_as_uint(x[e]);
+            const float r1 = x[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
+            mb[e] = __float_as_uint(r1);
+            lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e] & 0xFFFF0000u));
+          }
+          unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            hw[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);   // {hi16(odd), hi16(even)}
+            mw[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
+            lw[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
+          }
+          float* dst = a + (ld_row + i * RPP) * RS + st1_col;             // swizzled chunk of plane 0; planes are 16 floats apart
+          u32x4 t;
+          t.x = hw[0]; t.y = hw[1]; t.z = hw[2]; t.w = hw[3];
+          *reinterpret_cast<u32x4*>(dst) = t;
+          t.x = mw[0]; t.y = mw[1]; t.z = mw[2]; t.w = mw[3];
+          *reinterpret_cast<u32x4*>(dst + 16) = t;
+          t.x = lw[0]; t.y = lw[1]; t.z = lw[2]; t.w = lw[3];
+          *reinterpret_cast<u32x4*>(dst + 32) = t;
         }
 #pragma unroll
       for (int j = 0; j < NBC; ++j) {
@@ -540,7 +533,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const int b_row1 = (wn * TN * 32 + l31) * RS;
     const int rsw = (l31 >> 2) & 3;                  // rows of a wave's 32-row groups differ by multiples of 32
     const int rd1[2] = {((lh ^ rsw) << 2), (((2 + lh) ^ rsw) << 2)};
-    auto compute_at = [&](const float* a, const float* b) {
+    auto compute = [&](int buf) {
+      const float* a = sA1 + buf * BM * RS + a_row1;
+      const float* b = sB1 + buf * BN * RS + b_row1;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 fa[TM][3], fb[TN][3];
@@ -569,7 +564,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         if constexpr (TN >= 7) __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto compute = [&](int buf) { compute_at(sA1 + buf * BM * RS + a_row1, sB1 + buf * BN * RS + b_row1); };
     if constexpr (SPEC) {
       // chunk c sits in register stage c & 1 between its global loads and its LDS store, and in LDS buffer c & 1
       // afterwards.  Iteration ch: consumers compute from buffer ch & 1 while loaders store chunk ch+1 into the other
@@ -615,83 +609,12 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              // (with a fused GDN the C tile holds the finished convolution output, bias included)
-              const float bj = (GDN_CFG && P.gdn_w && P.bias) ? P.bias[(wn * TN + j) * 32 + l31] : 0.f;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sCf[row * (BN + 4) + wn * TN * 32 + j * 32 + l31] = (GDN_CFG && P.gdn_w && P.bias) ? acc[i][j][r] + bj : acc[i][j][r];
+                sCf[row * (BN + 4) + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
               }
-            }
-        }
-      }
-      if constexpr (GDN_CFG) {
-        if (P.gdn_w) {
-          // ---- fused GDN / IGDN (layers/gdn.py:62-75) behind the convolution: the tile holds all 192 channels of its
-          // 128 pixels, so  y = x * rsqrt(beta' + gamma' x^2)  (or x * sqrt(.))  is a second GEMM of the C tile against
-          // gamma' before anything leaves the block — the standalone 1x1 launch (read x, read x again, write y) and the
-          // convolution's own store of x disappear.  Same arithmetic as that launch, term for term: x^2 in fp32, exact
-          // bf16x3 split, six partial products per block in the same order, K in 32-channel chunks, + beta', 1/sqrtf or
-          // sqrtf, times x — bit-identical results (tests/test_gpu_ops.py::test_fused_gdn_is_bit_identical).
-          // LDS: C tile (fp32, with the row table) | one A stage (x^2 planes of 32 channels) | one B stage (gamma'
-          // planes of 32 input channels).  Loaders square / split the C tile's columns and stage gamma'; consumers
-          // multiply; two barriers per 32-channel chunk, the same count for both roles.
-          constexpr int LDC2 = BN + 4;
-          float* sC2 = smem;
-          float* sA2 = smem + BM * LDC2 + BM * 2;
-          float* sB2 = sA2 + BM * RS;
-          const unsigned long long gpa = reinterpret_cast<unsigned long long>(P.gdn_w);
-          const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(
-              reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(gpa >> 32)) << 32) |
-                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)gpa)), 0, 0x7FFFFFFF, 0x00020000);
-          if (!is_loader) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-          }
-          __syncthreads();                               // the C tile is complete
-          for (int kc = 0; kc < BN / 32; ++kc) {
-            if (is_loader) {
-              const unsigned wb2 = (unsigned)(kc * BN) * 192u;
-#pragma unroll
-              for (int j = 0; j < NBC; ++j) rb0[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g, (int)(b_goff[j] + wb2), 0, 0);
-#pragma unroll
-              for (int i = 0; i < NA; ++i) {
-                const int row = ld_row + i * RPP;
-                const float* src = sC2 + row * LDC2 + kc * 32 + ld_col;
-                const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
-                const float x[8] = {x0.x * x0.x, x0.y * x0.y, x0.z * x0.z, x0.w * x0.w, x1.x * x1.x, x1.y * x1.y, x1.z * x1.z, x1.w * x1.w};
-                split_store(sA2 + row * RS + st1_col, x);
-              }
-#pragma unroll
-              for (int j = 0; j < NBC; ++j)
-                if (b_loff[j] >= 0) *reinterpret_cast<u32x4*>(sB2 + b_loff[j]) = rb0[j];
-            }
-            __syncthreads();                             // stage kc is in LDS
-            if (!is_loader) compute_at(sA2 + a_row1, sB2 + b_row1);
-            __syncthreads();                             // ... and consumed
-          }
-          if (!is_loader) {
-            const bool inv = P.gdn_inv != 0;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const int col = (wn * TN + j) * 32 + l31;
-              const float bt = P.gdn_b[col];
-#pragma unroll
-              for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                  const float nrm = acc[i][j][r] + bt;
-                  const float g = inv ? sqrtf(nrm) : 1.0f / sqrtf(nrm);
-                  sC2[row * LDC2 + col] = g * sC2[row * LDC2 + col];
-                }
-            }
-          }
         }
       }
     } else if constexpr (NBUF == 2) {
@@ -928,7 +851,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         cch = n - ph * P.Cq;
         opix += (size_t)(ph >> 1) * P.Wf + (ph & 1);
       }
-      if (P.bias && !(GDN_CFG && P.gdn_w)) {
+      if (P.bias) {
         const float4 bb = *reinterpret_cast<const float4*>(P.bias + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
       }
@@ -1295,10 +1218,7 @@ static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
                                  : (size_t)2 * (BM + BN) * BK * sizeof(float);
   constexpr int crows = SPEC ? BM : WGM * 32;              // rows of C staged through LDS at a time
   constexpr size_t ctile = (size_t)crows * (BN + 4) * sizeof(float) + (size_t)crows * 2 * sizeof(int);
-  // the configuration that can carry a fused GDN keeps one A and one B stage behind the C tile for the second GEMM
-  constexpr size_t gdn2 = (SPEC && MODE == 1 && AIN == 0 && BM == 128 && BN == 192) ? ctile + (size_t)(BM + BN) * 48 * sizeof(float) : 0;
-  constexpr size_t smem0 = pipe > ctile ? pipe : ctile;
-  constexpr size_t smem = smem0 > gdn2 ? smem0 : gdn2;
+  constexpr size_t smem = pipe > ctile ? pipe : ctile;
   static_assert(smem <= 160 * 1024, "tile does not fit the CU's LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1418,7 +1338,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     ga.staged_epilogue = g_staged >= 0 ? g_staged : staged_env;
   }
   bool in_p3 = false, w16 = false, in16 = false;
-  int bk = 0, n_gdn = 0;
+  int bk = 0;
   long max_p = 0;
   int max_n = 0;
   double flops = 0, bytes = 0;
@@ -1524,15 +1444,6 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;
     p.post2 = c.post2.ptr; p.ld_post2 = c.post2.ld;
-    p.gdn_w = c.gdn_w; p.gdn_b = c.gdn_b; p.gdn_inv = c.gdn_inverse;
-    if (c.gdn_w) {
-      VAM_REQUIRE(conv_mode() == 1 && !c_w16 && !p3_in && !p3_out, "conv[%d]: a fused GDN needs the split-operand mode with fp32 tensors", i);
-      VAM_REQUIRE(c.N == 192 && c.gdn_b && c.act == VAM_ACT_NONE && !c.pre.ptr && !c.mul.ptr && !c.post.ptr && !c.post2.ptr &&
-                  !(c.flags & (VAM_CONV_PS2 | VAM_CONV_OUT_NCHW | VAM_CONV_SQUARE_IN)),
-                  "conv[%d]: a fused GDN follows a plain 192-channel convolution (bias only, NHWC fp32 output)", i);
-      VAM_REQUIRE((((uintptr_t)c.gdn_w) & 15) == 0 && (((uintptr_t)c.gdn_b) & 15) == 0, "conv[%d]: fused GDN operands not 16-byte aligned", i);
-      ++n_gdn;
-    }
     if (P > max_p) max_p = P;
     if (c.N > max_n) max_n = c.N;
     flops += 2.0 * (double)P * c.N * cin * c.kh * c.kw;
@@ -1595,7 +1506,6 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     double sc = padded / real * bp * cand[c].shape * kp;
     if (best_score < 0 || sc < best_score) { best_score = sc; bm = cand[c].bm; best_bn = cand[c].bn; }
   }
-  VAM_REQUIRE(n_gdn == 0 || n_gdn == nprob, "conv group: %d of %d problems carry a fused GDN (all or none)", n_gdn, nprob);
   if (g_force[0] == 64 || g_force[0] == 128) bm = g_force[0];
   if (g_force[1] > 0) best_bn = g_force[1];
   // K step 32 halves the barriers per FLOP; the sweep prefers 16 for the 128x192 tile (LDS for
@@ -1615,7 +1525,6 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     if (best_bn == 160) best_bn = (bm == 128) ? 96 : 64;
     if (bm == 64 && best_bn == 96) best_bn = 64;
   }
-  if (n_gdn) { bm = 128; best_bn = 192; }             // the one configuration with the second GEMM (wave-specialised, below)
   g_last[0] = bm; g_last[1] = best_bn; g_last[2] = bk;
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -1652,7 +1561,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       if (nc < min_chunks) min_chunks = nc;
     }
     const bool spec_tile = (bm == 64 && (best_bn == 32 || best_bn == 64 || best_bn == 128)) || (bm == 128 && (best_bn == 128 || best_bn == 192));
-    const bool spec = (bm == 128 && best_bn == 224) || n_gdn > 0 || (spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16));
+    const bool spec = (bm == 128 && best_bn == 224) || (spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16));
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
     if (bm == BM_ && best_bn == BN_) {                                                                      \
       if (spec) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 1>(ga, total, s)                  \

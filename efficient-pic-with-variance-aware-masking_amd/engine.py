@@ -18,8 +18,6 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -377,72 +375,32 @@ def lower_attention_blocks(plan: Plan, mods: Sequence[Ly.Win_noShift_Attention],
     return res
 
 
-FUSE_GDN = os.environ.get("VAMPIC_FUSE_GDN", "1") != "0"     # A/B and bit-identity tests: run every GDN as its own launch
-
-
-def _gdn_fusable(plan: Plan, n_out: int, gdn: Optional[Ly.GDN], *views) -> bool:
-    """A GDN / IGDN runs inside the producing convolution's launch (vam_conv.gdn_w) when that launch can be the
-    wave-specialised 128x192 tile: split-operand mode, 192 channels, fp32 tensors."""
-    return (FUSE_GDN and gdn is not None and ops.split_mode() and n_out == 192 and gdn.in_channels == 192 and
-            not any(isinstance(v, (ops.View16, ops.View3)) for v in views))
-
-
 def lower_deconv(plan: Plan, mods: Sequence[Ly.ConvTranspose2d], xs: Sequence[View], outs: Sequence[Optional[View]],
-                 act: int = L.ACT_NONE, out_nchw: Optional[Sequence[torch.Tensor]] = None,
-                 gdns: Optional[Sequence[Ly.GDN]] = None) -> List[Optional[View]]:
-    """``gdns``: the IGDN that follows each transposed convolution (models/builder.py:8-18); fused into the phase launches
-    where possible, otherwise lowered behind them."""
-    probs, res, later = [], [], []
+                 act: int = L.ACT_NONE, out_nchw: Optional[Sequence[torch.Tensor]] = None) -> List[Optional[View]]:
+    probs, res = [], []
     for i, (m, x) in enumerate(zip(mods, xs)):
         o = outs[i]
         nchw = out_nchw[i] if out_nchw is not None else None
-        g = gdns[i] if gdns is not None else None
-        if g is not None and o is not None:
-            raise ValueError("lower_deconv: a following GDN decides the output buffer")
         if o is None and nchw is None:
             o = plan.buf(x.B, 2 * x.H, 2 * x.W, m.out_channels)
         any16 = isinstance(x, ops.View16) or isinstance(o, ops.View16)
-        pks = m.packed(any16)
-        fuse = nchw is None and act == L.ACT_NONE and all(pk.n == 192 and pk.ps2_cq == 0 for pk in pks) and \
-            _gdn_fusable(plan, m.out_channels, g, x, o)
-        for pk in pks:
-            probs.append(ops.conv_problem(pk, [x], o, act, out_nchw=nchw, gdn=(g.packed(), g.inverse) if fuse else None))
+        for pk in m.packed(any16):
+            probs.append(ops.conv_problem(pk, [x], o, act, out_nchw=nchw))
         res.append(o)
-        later.append(None if (g is None or fuse) else g)
-    if gdns is not None and len({l is None for l in later}) > 1:
-        raise NotImplementedError("lower_deconv: fused and unfused GDNs in one group")
     plan.conv(probs)
-    if gdns is not None and later and later[0] is not None:
-        return lower_gdn(plan, later, res, [None] * len(res))
     return res
-
-
-def lower_conv_gdn(plan: Plan, convs: Sequence[Ly.Conv2d], gdns: Sequence[Ly.GDN], xs: Sequence[View]) -> List[View]:
-    """conv -> GDN pairs of the analysis transform (models/builder.py:43-53), K encoders in lockstep: one launch when the
-    GDN can ride in the convolution's block, two otherwise."""
-    fusable = FUSE_GDN and ops.split_mode() and not any(isinstance(x, (ops.View16, ops.View3)) for x in xs) and \
-        not (plan.act16 and any(_out_extent(c, x)[0] * _out_extent(c, x)[1] >= plan.act16_min_hw for c, x in zip(convs, xs)))
-    if fusable and all(_gdn_fusable(plan, c.out_channels, g, x) for c, g, x in zip(convs, gdns, xs)):
-        probs, res = [], []
-        for c, g, x in zip(convs, gdns, xs):
-            Ho, Wo, Co = _out_extent(c, x)
-            o = plan.buf(x.B, Ho, Wo, Co)
-            assert not isinstance(o, ops.View16)
-            probs.append(ops.conv_problem(c.packed(), [x], o, L.ACT_NONE, gdn=(g.packed(), g.inverse)))
-            res.append(o)
-        plan.conv(probs)
-        return res
-    t = lower_stacks(plan, [nn.Sequential(c) for c in convs], [[x] for x in xs], [None] * len(convs))
-    return lower_gdn(plan, gdns, t, [None] * len(convs))
 
 
 def lower_g_a(plan: Plan, encs: Sequence[nn.Sequential], x_s2d: View, ys: Sequence[View]):
     """models/builder.py:43-53, both encoders in lockstep; ys = 320-channel windows of y."""
     K = len(encs)
-    t = lower_conv_gdn(plan, [e[0] for e in encs], [e[1] for e in encs], [x_s2d] * K)
-    t = lower_conv_gdn(plan, [e[2] for e in encs], [e[3] for e in encs], t)
+    t = lower_stacks(plan, [nn.Sequential(e[0]) for e in encs], [[x_s2d]] * K, [None] * K)
+    t = lower_gdn(plan, [e[1] for e in encs], t, [None] * K)
+    t = lower_stacks(plan, [nn.Sequential(e[2]) for e in encs], [[v] for v in t], [None] * K)
+    t = lower_gdn(plan, [e[3] for e in encs], t, [None] * K)
     t = lower_attention_blocks(plan, [e[4] for e in encs], t, [None] * K)
-    t = lower_conv_gdn(plan, [e[5] for e in encs], [e[6] for e in encs], t)
+    t = lower_stacks(plan, [nn.Sequential(e[5]) for e in encs], [[v] for v in t], [None] * K)
+    t = lower_gdn(plan, [e[6] for e in encs], t, [None] * K)
     t = lower_stacks(plan, [nn.Sequential(e[7]) for e in encs], [[v] for v in t], [None] * K)
     return lower_attention_blocks(plan, [e[8] for e in encs], t, ys)
 
@@ -452,10 +410,13 @@ def lower_g_s(plan: Plan, decs: Sequence[nn.Sequential], ys: Sequence[View], x_h
     """models/builder.py:8-18 (+ clamp_(0,1) of pic.py:558,651), result stored NCHW."""
     K = len(decs)
     t = lower_attention_blocks(plan, [d[0] for d in decs], ys, [None] * K)
-    t = lower_deconv(plan, [d[1] for d in decs], t, [None] * K, gdns=[d[2] for d in decs])
-    t = lower_deconv(plan, [d[3] for d in decs], t, [None] * K, gdns=[d[4] for d in decs])
+    t = lower_deconv(plan, [d[1] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[2] for d in decs], t, [None] * K)
+    t = lower_deconv(plan, [d[3] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[4] for d in decs], t, [None] * K)
     t = lower_attention_blocks(plan, [d[5] for d in decs], t, [None] * K)
-    t = lower_deconv(plan, [d[6] for d in decs], t, [None] * K, gdns=[d[7] for d in decs])
+    t = lower_deconv(plan, [d[6] for d in decs], t, [None] * K)
+    t = lower_gdn(plan, [d[7] for d in decs], t, [None] * K)
     lower_deconv(plan, [d[8] for d in decs], t, [None] * K, L.ACT_CLAMP01 if clamp else L.ACT_NONE, out_nchw=x_hat)
 
 

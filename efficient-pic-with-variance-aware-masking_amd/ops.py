@@ -279,15 +279,9 @@ def _aux(v: Optional[View]) -> L.VamAux:
 
 def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT_NONE, *,
                  pre: Optional[View] = None, mul: Optional[View] = None, post: Optional[View] = None,
-                 post2: Optional[View] = None, flags: int = 0, out_nchw: Optional[torch.Tensor] = None,
-                 gdn: Optional[tuple] = None) -> L.VamConv:
-    """Describe one problem.  ``inputs`` are concatenated along channels (virtually).  ``gdn`` = (packed GDN layer,
-    inverse): the GDN / IGDN that follows this 192-channel convolution runs inside the same launch (vam_conv.gdn_w)."""
+                 post2: Optional[View] = None, flags: int = 0, out_nchw: Optional[torch.Tensor] = None) -> L.VamConv:
+    """Describe one problem.  ``inputs`` are concatenated along channels (virtually)."""
     c = L.VamConv()
-    if gdn is not None:
-        gpk, ginv = gdn
-        assert gpk.n == 192 and gpk.cin == 192 and pk.n == 192 and not gpk.w16
-        c.gdn_w, c.gdn_b, c.gdn_inverse = gpk.w.data_ptr(), gpk.b.data_ptr(), int(bool(ginv))
     assert 1 <= len(inputs) <= L.VAM_MAX_SEG
     in3 = isinstance(inputs[0], View3)
     assert all(isinstance(v, View3) == in3 for v in inputs), "a conv problem reads either fp32 or bf16x3-plane segments"

@@ -110,15 +110,6 @@ typedef struct vam_conv {
   int32_t act;              /* enum vam_act                                           */
   int32_t flags;            /* enum vam_conv_flags                                    */
   vam_aux pre, mul, post, post2;
-  /* Optional fused GDN / IGDN behind the convolution (layers/gdn.py:62-75; g_a / g_s: every 192-channel conv or
-   * transposed-conv phase that a GDN follows): out = v * rsqrt(beta' + gamma' v^2) (or v * sqrt(.) with gdn_inverse),
-   * v = conv + bias, computed inside the block before anything is stored — bit-identical to the separate 1x1 launch
-   * (VAM_CONV_SQUARE_IN problem with mul = v).  gdn_w = packed gamma' (vam_pack_conv_weights, VAM_PACK_GDN, 1x1,
-   * 192 -> 192), gdn_b = beta' (vam_pack_bias, VAM_PACK_GDN).  Requirements: split-operand mode, N == 192, act NONE, no
-   * pre/mul/post operands, NHWC fp32 output (strided views allowed); all problems of a group or none. */
-  const float* gdn_w;
-  const float* gdn_b;
-  int32_t gdn_inverse;
 } vam_conv;
 
 /* sizeof(vam_conv) as compiled into the library (binding layout guard). */
