@@ -354,6 +354,11 @@ def test_refine_gs_epoch_driver(pic_model):
             return float(torch.nn.functional.mse_loss(x, m.eval().forward_single_quality(x, 2.5)["x_hat"]))
     before = fixed_loss()
     opt = torch.optim.Adam(params, lr=1e-4)
-    counter, loss, bpp, mse, bpp_s = FT.train_one_epoch_refine_gs(m, crit, [x] * 8, opt, epoch=0, counter=0, rng=random.Random(3))
-    assert counter == 8 and math.isfinite(loss) and loss > 0 and bpp > 0 and bpp_s == 0.0 and mse > 0
+    # (a) the sampled schedule runs: one quality of the reference's list per step
+    counter, loss, bpp, mse, bpp_s = FT.train_one_epoch_refine_gs(m, crit, [x] * 3, opt, epoch=0, counter=0, rng=random.Random(3))
+    assert counter == 3 and math.isfinite(loss) and loss > 0 and bpp > 0 and bpp_s == 0.0 and mse > 0
+    # (b) and it optimises: a dozen steps at ONE quality lower that quality's distortion (a handful of Adam steps at
+    #     randomly sampled qualities need not lower the distortion at a fixed one)
+    counter, loss, _, _, _ = FT.train_one_epoch_refine_gs(m, crit, [x] * 12, opt, epoch=1, counter=counter, list_quality=[2.5])
+    assert counter == 15 and math.isfinite(loss)
     assert fixed_loss() < before
