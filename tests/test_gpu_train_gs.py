@@ -362,3 +362,34 @@ def test_refine_gs_epoch_driver(pic_model):
     counter, loss, _, _, _ = FT.train_one_epoch_refine_gs(m, crit, [x] * 12, opt, epoch=1, counter=counter, list_quality=[2.5])
     assert counter == 15 and math.isfinite(loss)
     assert fixed_loss() < before
+
+
+def test_training_step_is_reproducible_under_graph_replay(pic_model):
+    """Thirty replays of the captured forward + backward graphs at FIXED parameters must give the same gradients every
+    time (bit for bit, except the two relative-position-bias tables, which are summed with float atomics: 1e-6).
+    Regression test: a hipMemsetAsync node in front of the attention-table atomics intermittently left garbage (1e14 ...
+    1e33) in single table elements under graph replay, which zeroed every other gradient through clip_grad_norm_ and made
+    the refine_gs --lrp loop diverge after a few steps; the clear is a kernel node now (vam_memset_zero)."""
+    net0, sd = pic_model
+    m = copy.deepcopy(net0).train()
+    m.use_graph = True
+    m.freeze_all()
+    m.unfreeze_decoder(lrp=True)
+    x = synth.synth_image(2, 64, 64, seed=8).cuda()
+    ref = None
+    for it in range(30):
+        m.zero_grad(set_to_none=True)
+        out = m.forward_single_quality(x, quality=2.5, training=True)
+        _distortion_loss(out, x).backward()
+        g = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        junk = [torch.randn(1 << 20, device="cuda") for _ in range(4)]          # allocator churn, as an optimiser causes
+        del junk
+        if ref is None:
+            ref = g
+            continue
+        for n in g:
+            assert torch.isfinite(g[n]).all(), (it, n)
+            if n.endswith("relative_position_bias_table"):
+                assert (g[n] - ref[n]).abs().max().item() <= 1e-6 * ref[n].abs().max().item(), (it, n)
+            else:
+                assert torch.equal(g[n], ref[n]), (it, n)
