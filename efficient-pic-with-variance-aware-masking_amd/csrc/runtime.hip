@@ -133,7 +133,12 @@ int vam_graph_launch(void* exec, void* stream) {
 }
 
 int vam_graph_destroy(void* exec) {
-  if (exec) VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  if (exec) {
+    // a plan that is dropped (weights edited, storage mode switched) may still have replays in flight: the executable
+    // graph must outlive them (destroying it under a running launch crashed a later hipGraphLaunch, intermittently)
+    (void)hipDeviceSynchronize();
+    VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  }
   return VAM_OK;
 }
 
