@@ -266,7 +266,9 @@ def _deconv_bwd(bw, pk, r: dict, dy: View, grads, need_dx: bool = True) -> Optio
         tb = torch.zeros((dy.C,), dtype=torch.float32, device=gw.device)
         bw.keep += [tw, tb]
         bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2))
-        bw.call(lambda: (ops.colsum(dy, tb), gw.copy_(tw[:, :co]), gb.copy_(tb[:co])), "deconv bias grad + unpad")
+        # (torch.mul(.., 1.0, out=..) instead of a contiguous copy_: an element-wise KERNEL node under graph capture, not a
+        # device-to-device memcpy node — see vam_memset_zero for what a non-kernel node did in these graphs)
+        bw.call(lambda: (ops.colsum(dy, tb), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
     if not need_dx:
         return None
     dx = bw.buf(x.B, x.H, x.W, ci)
