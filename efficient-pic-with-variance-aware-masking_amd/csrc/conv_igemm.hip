@@ -21,7 +21,8 @@
 //   coalesced 16-byte buffer loads, zero-filled at the halo by the hardware range check, staged through LDS; the next
 //   chunk is prefetched into registers under the MFMAs.
 // * Canonical K order (32-channel group outer, tap inner): a layer gives bit-identical results however it is tiled
-//   or grouped (the decoder must reproduce the encoder's sigma exactly).
+//   or grouped (the decoder must reproduce the encoder's sigma exactly).  16-channel inputs (the space-to-depth RGB
+//   layer) put two consecutive taps into one 32-channel chunk instead of padding each tap with 16 zero channels.
 // * Grouped launch: up to 8 independent problems share one grid; every XCD gets a contiguous eighth of EACH problem's
 //   tiles (blocks b and b+8 share an XCD/L2) so neighbours reuse A rows and halos.
 // * The C tile is staged through LDS in 32-row slabs so the epilogue issues 16-byte loads / stores.
@@ -61,6 +62,7 @@ struct ConvP {
   int tiles_n;
 };
 
+constexpr int VAM_CONVI_DUAL = 1 << 29;     // internal ConvP flag: 16-channel input, two taps share one 32-channel K chunk (split-operand mode)
 constexpr int VAM_CONVI_STAGED = 1 << 30;   // internal ConvP flag: tensor extents beyond the direct epilogue's 32-bit window
 
 struct GroupArgs {
@@ -224,7 +226,10 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   int s_begin = 0, s_end = 0, s_ld4 = 0;     // current input segment (see gload)
   unsigned s_lo = 0, s_hi = 0;
   const int n_taps = u_kh * u_kw;
-  const int n_chunks = n_taps * u_Kc;        // Kc = K chunks of BK per tap
+  // 16-channel inputs (the space-to-depth RGB layer): a 32-channel K chunk would be half zeros, so two consecutive taps
+  // share one (units 0-1 of a row: tap 2c, units 2-3: tap 2c+1); the weights are packed the same way
+  const bool dual = MODE == 1 && (P.flags & VAM_CONVI_DUAL) != 0;
+  const int n_chunks = dual ? (n_taps + 1) / 2 : n_taps * u_Kc;        // Kc = K chunks of BK per tap
   // fp32 NHWC outputs with fp32 epilogue operands leave straight from the accumulators (epilogue, "direct" path) in the
   // one configuration where that measured faster (see there)
   constexpr bool DIRECT_CFG = !SPEC && BM == 128 && BN == 64;
@@ -450,30 +455,43 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       }
       const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<void*>(((unsigned long long)s_hi << 32) | s_lo), 0, 0x7FFFFFFF, 0x00020000);
-      const int tap_pix = c_ty * u_W + c_tx;
+      int tap_pix = c_ty * u_W + c_tx;
       // byte offset of this thread's 8 channels inside a pixel: 32 B of fp32, or one 48-byte P3 group
-      const int col4 = AIN ? ((cc0 - s_begin + ld_col) >> 3) * 48 : (cc0 - s_begin + ld_col) * 4;
-      const bool ch_ok = cc0 + ld_col < u_Cin;       // the last chunk of a 16-mod-32 channel count is half empty
+      int col4 = AIN ? ((cc0 - s_begin + ld_col) >> 3) * 48 : (cc0 - s_begin + ld_col) * 4;
+      bool ch_ok = cc0 + ld_col < u_Cin;             // the last chunk of a 16-mod-32 channel count is half empty
+      int my_tap = c_tap;
+      if (!AIN && dual) {                            // (block-uniform) this thread's half of the chunk belongs to tap c_tap or c_tap + 1
+        const bool second = ld_col >= 16;
+        const int txb = (c_tx + 1 == u_kw) ? 0 : c_tx + 1, tyb = (c_tx + 1 == u_kw) ? c_ty + 1 : c_ty;
+        tap_pix = second ? tyb * u_W + txb : tap_pix;
+        my_tap = second ? c_tap + 1 : c_tap;
+        col4 = (ld_col & 15) * 4;
+        ch_ok = my_tap < n_taps;
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const bool ok = ch_ok && ((a_mask[i] >> c_tap) & 1u);
+        const bool ok = ch_ok && ((a_mask[i] >> my_tap) & 1u);
         const unsigned off = ok ? (unsigned)((a_pix0[i] + tap_pix) * s_ld4 + col4) : 0x80000000u;
 #pragma unroll
         for (int q = 0; q < NAR; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)(off + 16u * q), 0, 0);
       }
       // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
-      const unsigned wbase = (unsigned)((c_tap * u_Kc + c_kc) * u_Npad) * 192u;
+      // (dual: [tap pair][Npad][...], the pair's two 16-channel halves side by side)
+      const unsigned wbase = (unsigned)((dual ? (c_tap >> 1) : (c_tap * u_Kc + c_kc)) * u_Npad) * 192u;
 #pragma unroll
       for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
       // canonical K order: 32-channel group OUTER, tap INNER
-      ++c_tap;
-      ++c_tx;
-      const int wx = (c_tx == u_kw) ? 1 : 0;
-      c_tx = wx ? 0 : c_tx;
-      c_ty += wx;
-      const int wt = (c_tap == n_taps) ? 1 : 0;
+      for (int step = 0; step < (dual ? 2 : 1); ++step) {
+        ++c_tap;
+        ++c_tx;
+        const int wx = (c_tx == u_kw) ? 1 : 0;
+        c_tx = wx ? 0 : c_tx;
+        c_ty += wx;
+      }
+      const int wt = (c_tap >= n_taps) ? 1 : 0;
       c_tap = wt ? 0 : c_tap;
       c_ty = wt ? 0 : c_ty;
+      c_tx = wt ? 0 : c_tx;
       c_kc += wt;
     };
     static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
@@ -1131,7 +1149,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
 // bf16x3 layout: [tap][32-channel chunk][Npad][12 chunks][8 bf16]; chunk (p*4 + g) holds plane p (hi/mid/lo) of
 // channels 8g..8g+7 of the 32-channel chunk.  The three planes sum to the fp32 weight exactly.
 __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
-                                        int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total) {
+                                        int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total, int dual) {
   long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= total) return;
   int kk = (int)(d % 32);
@@ -1140,15 +1158,19 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   r /= npad;
   int c_chunk = (int)(r % kc32);
   int tap = (int)(r / kc32);
-  int ty = tap / kw, tx = tap % kw;
   int cc = c_chunk * 32 + kk;
-  const float v = pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx);
+  if (dual) {                                    // 16 input channels: chunk = tap pair, [tap 2c: 16 ch | tap 2c+1: 16 ch]
+    tap = 2 * tap + (kk >> 4);
+    cc = kk & 15;
+  }
+  int ty = tap / kw, tx = tap % kw;
+  const float v = (tap < kh * kw) ? pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx) : 0.f;
   // exact split by truncation (same as the activations' in the kernel): hi + mid + lo == v
   const unsigned hb = __float_as_uint(v);
   const float r1 = v - __uint_as_float(hb & 0xFFFF0000u);
   const unsigned mb = __float_as_uint(r1);
   const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb & 0xFFFF0000u));
-  const size_t row = ((size_t)(tap * kc32 + c_chunk) * npad + nn) * 96;      // 96 bf16 = 192 B per row
+  const size_t row = (size_t)(d / 32) * 96;                                  // 96 bf16 = 192 B per (chunk, n) row
   const int g = kk >> 3, e = kk & 7;
   dst[row + (0 * 4 + g) * 8 + e] = (unsigned short)(hb >> 16);
   dst[row + (1 * 4 + g) * 8 + e] = (unsigned short)(mb >> 16);
@@ -1198,6 +1220,8 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restric
 static int g_force[3] = {0, 0, 0};   // tuning hook: forced BM / BN / BK (0 = automatic)
 static int g_staged = -1;             // tuning / test hook: 1 = staged epilogue everywhere, 0 = automatic, -1 = VAMPIC_EPILOGUE
 static int g_last[3] = {0, 0, 0};   // tile configuration of the most recent launch (diagnostics)
+
+static inline bool dual_tap(int cin, int taps) { return cin == 16 && taps > 1; }   // split-operand mode: see VAM_CONVI_DUAL
 
 static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
 
@@ -1288,9 +1312,10 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int
   int npad = (n + 31) / 32 * 32;
   if (conv_mode() == 1) {
     const int kc32 = (cin + 31) / 32;
-    const long total1 = (long)kh * kw * kc32 * npad * 32;
+    const int dual = dual_tap(cin, kh * kw) ? 1 : 0;       // 16-channel inputs: two taps per 32-channel chunk (kernel: VAM_CONVI_DUAL)
+    const long total1 = dual ? (long)((kh * kw + 1) / 2) * npad * 32 : (long)kh * kw * kc32 * npad * 32;
     hipLaunchKernelGGL(pack_weights_bf3_kernel, dim3(cdiv(total1, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       reinterpret_cast<unsigned short*>(dst), mode, phase, kh, kw, cin, n, npad, kc32, total1);
+                       reinterpret_cast<unsigned short*>(dst), mode, phase, kh, kw, cin, n, npad, kc32, total1, dual);
     return check_launch("pack_weights_bf3_kernel");
   }
   int bk = PK;
@@ -1427,6 +1452,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
     p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
     p.Cq = c.Cq; p.act = c.act; p.flags = c.flags;
+    if (conv_mode() == 1 && !c_w16 && !p3_in && c.n_seg == 1 && dual_tap(cin, c.kh * c.kw)) p.flags |= VAM_CONVI_DUAL;
     {
       // the kernel addresses every input segment with 32-bit byte offsets inside a 2^31-byte window
       const double in_pix = (double)c.B * c.H * c.W;
