@@ -166,3 +166,31 @@ def test_image_io_round_trip(tmp_path):
     write_image(x, p)
     y = read_image(p)
     assert y.dtype == torch.float32 and y.shape == (3, 20, 31) and torch.equal(y, x)
+
+
+def test_finetune_driver_host_logic():
+    """Host side of the two training schedules (vampic.finetune): the quality lists of train.py:150-155 / :167-181, the
+    check-level lookup of training/step.py:14-32, and the two criteria (training/loss.py:126-187, 189-229) on a synthetic
+    output dict — formulas restated inline."""
+    import math
+    import numpy as np
+    import torch
+    from vampic import finetune as FT
+    q = FT.refine_gs_quality_list()
+    exp = list(np.arange(0.015, 1.5, (1.5 - 0.025) / 200)) + [1.5] + list(np.arange(1.6, 10, (10 - 1.6) / 50)) + [10]
+    assert q == [float(v) for v in exp] and q[0] == 0.015 and q[-1] == 10.0
+    assert FT.extract_quality_ref(0.5, [0.75]) is None and FT.extract_quality_ref(2.5, [0.75]) == 0.75
+    assert FT.extract_quality_ref(1.0, [0.75, 2.0]) == 0.75 and FT.extract_quality_ref(5.0, [0.75, 2.0]) == 2.0
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((2, 3, 8, 8), generator=g)
+    out = {"x_hat": torch.rand((2, 3, 8, 8), generator=g).requires_grad_(True),
+           "likelihoods": {"y": torch.rand((2, 4, 2, 2), generator=g) * 0.9 + 0.05, "z": torch.rand((2, 3, 1, 1), generator=g) * 0.9 + 0.05}}
+    den = -math.log(2) * 2 * 8 * 8
+    d = FT.DistortionLoss(device="cpu")(out, x, lmbda=1e-2)
+    mse = torch.nn.functional.mse_loss(x, out["x_hat"])
+    assert torch.allclose(d["loss"], 255.0 ** 2 * 1e-2 * mse) and float(d["bpp_scalable"]) == 0.0
+    assert torch.allclose(d["bpp_loss"], torch.log(out["likelihoods"]["y"]).sum() / den + 2 * torch.log(out["likelihoods"]["z"]).sum() / den)
+    d["loss"].backward()
+    assert out["x_hat"].grad is not None                       # the distortion is the trained term
+    r = FT.RateLoss(device="cpu")(out, x)
+    assert torch.allclose(r["loss"], torch.log(out["likelihoods"]["y"]).sum() / den + 2 * torch.log(out["likelihoods"]["z"]).sum() / den)
