@@ -330,6 +330,76 @@ def main():
     pic.zero_grad(set_to_none=True)
     pic.eval()
 
+    # 10. first-stage training (BASELINE configs[3], `--training_type first_train`, train.py:146-149): the reference's own
+    #     ``forward(x, quality=[0, 10])`` in training mode, ScalableRateDistortionLoss (training/loss.py:6-66, the parser's
+    #     default --lmbda_list) and backward with EVERY parameter trainable; then one single-quality training pass
+    #     (``forward_single_quality(x, 2.5, training=True)``: mask, clamp and straight-through paths with a non-trivial mask)
+    #     under the same criterion with an explicit lmbda.  Noise injected as in section 6.
+    pic.train()
+    for p_ in pic.parameters():
+        p_.requires_grad = True
+    pic.zero_grad(set_to_none=True)
+    xt = synth.synth_image(2, 64, 64, seed=5)
+    ny = synth.uniform((2, 640, 4, 4), 201) - 0.5
+    nz = synth.uniform((2, 192, 1, 1), 202) - 0.5
+
+    def with_noise(fn):
+        queue = [nz.transpose(0, 1).reshape(192, 1, -1)] + list(ny.chunk(20, 1))
+        real = torch.Tensor.uniform_
+
+        def fake(self, a=0.0, b=1.0):
+            src = queue.pop(0)
+            assert tuple(src.shape) == tuple(self.shape) and (a, b) == (-0.5, 0.5), (src.shape, self.shape, a, b)
+            with torch.no_grad():
+                return self.copy_(src)
+        torch.Tensor.uniform_ = fake
+        try:
+            r = fn()
+        finally:
+            torch.Tensor.uniform_ = real
+        assert not queue
+        return r
+
+    def grad_record(net_, stride):
+        names, norms, samples = [], [], []
+        for k, p_ in net_.named_parameters():
+            if p_.grad is None:
+                continue
+            gflat = p_.grad.detach().reshape(-1)
+            names.append(k)
+            norms.append(gflat.double().norm().item())
+            samples.append(gflat[::stride].numpy())
+        return {"grad_names": np.array(names), "grad_norms": np.array(norms, dtype=np.float64),
+                "grad_samples": np.concatenate(samples).astype(np.float32)}
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                # the criterion's broadcasting mse_loss (training/loss.py:41)
+        o = with_noise(lambda: pic(xt, quality=[0, 10], training=True))
+        crit = loss_mod2.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device="cpu")(o, xt)
+        crit["loss"].backward()
+        rec = {"loss": np.array([crit[k].mean().item() for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype")], dtype=np.float64),
+               "mse": crit["mse_loss"].detach().double().numpy(),
+               "x_hat": o["x_hat"].detach()[:, :, :, ::4, ::4].numpy(), "lik_y": o["likelihoods"]["y"].detach().numpy(),
+               "lik_y_prog": o["likelihoods"]["y_prog"].detach().numpy(), "lik_z": o["likelihoods"]["z"].detach().numpy(),
+               "y_hat_base": o["y_hat"][0].detach().numpy(), "y_hat_prog": o["y_hat"][1].detach().numpy()}
+        rec.update(grad_record(pic, 997))
+        unused = [k for k, p_ in pic.named_parameters() if p_.grad is None]
+        assert not unused, unused
+        np.savez_compressed(os.path.join(GOLD, "first_train_step.npz"), **rec)
+        pic.zero_grad(set_to_none=True)
+        o = with_noise(lambda: pic.forward_single_quality(xt, quality=2.5, training=True))
+        crit = loss_mod2.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device="cpu")(o, xt, lmbda=0.01)
+        crit["loss"].backward()
+        rec = {"loss": np.array([crit[k].mean().item() for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype")], dtype=np.float64),
+               "mse": crit["mse_loss"].detach().double().numpy(),
+               "x_hat": o["x_hat"].detach()[:, :, ::4, ::4].numpy(), "lik_y": o["likelihoods"]["y"].detach().numpy(),
+               "lik_z": o["likelihoods"]["z"].detach().numpy(), "y_hat": o["y_hat"].detach().numpy()}
+        rec.update(grad_record(pic, 997))
+        np.savez_compressed(os.path.join(GOLD, "train_single_step.npz"), **rec)
+    pic.zero_grad(set_to_none=True)
+    pic.eval()
+
     # 9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each
     #    (q = 0 and q = 2.5; REM variants with a checkpoint latent at their first check level).  Weights: the same
     #    name-keyed synthetic generator, so the shared modules carry the same values in every variant.

@@ -722,3 +722,154 @@ def refine_gs_training_step(sd: SD, x: Tensor, quality: float, *, lmbda: float =
     grads = {(k[len(prefix):] if k.startswith(prefix) else k): v.grad for k, v in leaves.items()
              if k.startswith(trained) and torch.is_tensor(v) and v.grad is not None}
     return loss.detach(), mse.detach(), x_hat.detach(), grads
+
+
+# --------------------------------------------------------------------------
+# A.11 first-stage training step (BASELINE configs[3], `--training_type first_train`, train.py:146-149):
+#      ``VarianceMaskingPIC.forward(x, quality=[0, q], training=True)`` (models/pic.py:301-491) or
+#      ``forward_single_quality(x, q, training=True)`` (:497-666) with EVERY parameter trainable,
+#      ``ScalableRateDistortionLoss`` (training/loss.py:6-66), autograd over this restatement.
+# --------------------------------------------------------------------------
+def ste_round(x: Tensor) -> Tensor:
+    """models/utils.py:4-5: value round(x), gradient identity."""
+    return torch.round(x) - x.detach() + x
+
+
+def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, *,
+                     single: bool = False, div: int = 320, chunk: int = 32, max_support: int = 5,
+                     prog_support: int = 5) -> dict:
+    """Training-mode forward, README flags (dual encoder / decoder / hyperprior, delta_encode, total_mu_rep,
+    all_scalable).  ``single`` = False: ``forward(x, quality=[0, q])`` — both decoders, no clamp, likelihoods
+    {"y": base, "y_prog": [1, B, 640] = base AND progressive (pic.py:389-390,471-472), "z"}.  ``single`` = True:
+    ``forward_single_quality(x, q)`` — the decoder in use, ``clamp_(0, 1)``, likelihoods {"y", "z"}.  ``noise_y`` [B,640,h,w]
+    / ``noise_z`` [B,192,h/4,w/4]: the U(-.5,.5) draws of quantize("noise") (entropy_models.py:132-138)."""
+    qs = list(qualities)
+    assert (single and len(qs) == 1) or (not single and len(qs) == 2 and qs[0] == 0)
+    q = qs[-1]
+    base_only = single and q == 0
+    y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)                       # pic.py:309-311
+    z = h_a(sd, y)                                                                       # :280
+    z_lik = eb_likelihood_noise_bounded(sd, z, noise_z)
+    med = sd["entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    z_hat = ste_round(z - med) + med                                                     # :282-284
+    if base_only:                                                                        # :285-288 (quality == 0)
+        means_h, scales_h = h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_scale_s.0.", z_hat)
+    else:
+        means_h = torch.cat([h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_mean_s.1.", z_hat)], 1)
+        scales_h = torch.cat([h_s(sd, "h_scale_s.0.", z_hat), h_s(sd, "h_scale_s.1.", z_hat)], 1)
+    ns0 = div // chunk
+    ys = y.chunk(y.shape[1] // chunk, 1)
+    nys = noise_y.chunk(noise_y.shape[1] // chunk, 1)
+    yhat_b, lik_b, mu_b, std_b = [], [], [], []
+    for i in range(ns0):                                                                 # :330-367
+        sup = yhat_b[:min(max_support, i)]
+        msup = torch.cat([means_h[:, :div]] + sup, 1)
+        ssup = torch.cat([scales_h[:, :div]] + sup, 1)
+        mu = cc_stack(sd, f"cc_mean_transforms.{i}.", msup)
+        sc = cc_stack(sd, f"cc_scale_transforms.{i}.", ssup)
+        mu_b.append(mu)
+        std_b.append(sc)
+        lik_b.append(gaussian_likelihood_noise(ys[i], sc, mu, nys[i]))
+        yh = ste_round(ys[i] - mu) + mu
+        lrp = cc_stack(sd, f"lrp_transforms.{i}.", torch.cat([msup, yh], 1))
+        yhat_b.append(yh + 0.5 * torch.tanh(lrp))
+    y_base = torch.cat(yhat_b, 1)
+    out = {"y_base": y_base, "y": y, "z": z, "mu_base": torch.cat(mu_b, 1), "std_base": torch.cat(std_b, 1)}
+    lik_base = torch.cat(lik_b, 1)
+    x_hats = []
+    if not single or base_only:
+        xb = g_s(sd, "g_s.0.", y_base)                                                   # :372
+        x_hats.append(xb.clamp(0, 1) if single else xb)
+    if base_only:
+        out.update({"x_hat": x_hats[0], "likelihoods": {"y": lik_base, "z": z_lik}, "y_hat": y_base})
+        return out
+    mu_tot, std_tot, lik_p, yhat_p, masks, mu_p, std_p = [], [], [], [], [], [], []
+    for j in range(ns0):                                                                 # :396-457
+        r = ys[ns0 + j] - ys[j]
+        s = min(prog_support, j)
+        msup = torch.cat([means_h[:, div:], yhat_b[j]] + mu_tot[j - s:j], 1)
+        ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + std_tot[j - s:j], 1)
+        mu = cc_stack(sd, f"cc_mean_transforms_prog.{j}.", msup)
+        sc = cc_stack(sd, f"cc_scale_transforms_prog.{j}.", ssup)
+        mu_tot.append(mu + yhat_b[j])
+        std_tot.append(sc)
+        mu_p.append(mu)
+        std_p.append(sc)
+        m = variance_mask(sc.detach(), q)                                                # hard comparison: no gradient (channel_mask.py:132-151)
+        masks.append(m)
+        lik_p.append(gaussian_likelihood_noise((r - mu) * m, sc * m, None, nys[ns0 + j]))
+        rh = ste_round(r - mu) * m + mu                                                  # :443
+        lrp = cc_stack(sd, f"lrp_transforms_prog.{j}.", torch.cat([msup, rh], 1))
+        yhat_p.append(rh + 0.5 * torch.tanh(lrp) + yhat_b[j])
+    y_prog = torch.cat(yhat_p, 1)
+    xp = g_s(sd, "g_s.1.", y_prog)
+    x_hats.append(xp.clamp(0, 1) if single else xp)
+    lik_all = torch.cat([lik_base] + lik_p, 1)
+    out.update({"y_hat": y_prog, "y_prog": y_prog, "mask": torch.cat(masks, 1), "mu": torch.cat(mu_p, 1),
+                "std": torch.cat(std_p, 1)})
+    if single:
+        out.update({"x_hat": x_hats[0], "likelihoods": {"y": lik_all, "z": z_lik}})
+    else:
+        out.update({"x_hat": torch.stack(x_hats, 0), "likelihoods": {"y": lik_base, "y_prog": lik_all.unsqueeze(0), "z": z_lik}})
+    return out
+
+
+def eb_likelihood_noise_bounded(sd: SD, z: Tensor, noise: Tensor, prefix: str = "entropy_bottleneck.") -> Tensor:
+    """``eb_likelihood_noise`` with the likelihood bound as compressai's LowerBound (gradient rule) instead of a clamp, and
+    the sign detached as the reference detaches it (entropy_models.py:431-432,477-478) — same values."""
+    B, C = z.shape[:2]
+    out = (z + noise).transpose(0, 1).contiguous().reshape(C, 1, -1)
+    lower = eb_logits_cumulative(sd, out - 0.5, prefix)
+    upper = eb_logits_cumulative(sd, out + 0.5, prefix)
+    sign = (-torch.sign(lower + upper)).detach()
+    lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    lik = lower_bound(lik, LIKELIHOOD_BOUND)
+    return lik.reshape((C, B) + tuple(z.shape[2:])).transpose(0, 1).contiguous()
+
+
+def scalable_rd_loss(out: dict, target: Tensor, lmbda, weight: float = 255.0 ** 2) -> dict:
+    """``ScalableRateDistortionLoss.forward`` (training/loss.py:17-66), including its accounting: the base rate enters twice
+    when "y_prog" is present and ``batch_size_recon`` = x_hat.shape[0] (the number of LEVELS for the stacked
+    output of ``forward``, the number of IMAGES for a single-quality output) multiplies the hyperprior rate."""
+    B, _, H, W = target.shape
+    n_rec = out["x_hat"].shape[0]
+    tgt = target.unsqueeze(0)
+    if n_rec != 1 and n_rec != B:
+        tgt = tgt.repeat(n_rec, 1, 1, 1, 1)
+    lm = torch.as_tensor(lmbda, dtype=torch.float32).reshape(-1)
+    res = {"mse_loss": F.mse_loss(tgt, out["x_hat"], reduction="none").mean(dim=(1, 2, 3, 4))}
+    den = -math.log(2) * B * H * W
+    lik = out["likelihoods"]
+    res["bpp_hype"] = torch.log(lik["z"]).sum() / den
+    if "y_prog" in lik:
+        res["bpp_base"] = torch.log(lik["y"]).sum() / den
+        res["bpp_scalable"] = torch.log(lik["y_prog"]).sum() / den
+    else:
+        res["bpp_base"] = torch.log(lik["y"].squeeze(0)).sum() / den
+        res["bpp_scalable"] = torch.log(lik["y"]).sum() / den * 0.0
+    res["bpp_loss"] = res["bpp_scalable"] + res["bpp_base"] + n_rec * res["bpp_hype"]
+    res["loss"] = res["bpp_loss"] + weight * (lm * res["mse_loss"]).mean()
+    return res
+
+
+def first_train_step(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, lmbda, *,
+                     single: bool = False, trainable=None) -> dict:
+    """One optimisation step's forward + backward with every floating-point parameter trainable (``trainable``: a
+    predicate on the key name; default all).  Returns the forward outputs (detached), the loss terms and
+    {name: gradient} — None where autograd left no gradient (a parameter the pass does not use)."""
+    skip = ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length",
+            "gaussian_conditional.")
+    leaves = {}
+    for k, v in sd.items():
+        if torch.is_tensor(v) and v.dtype.is_floating_point and not k.startswith(skip) and "reparam" not in k and \
+                not k.endswith((".target", ".bound", ".pedestal")) and not k.startswith("post_latent.") and \
+                (trainable is None or trainable(k)):
+            leaves[k] = v.detach().clone().requires_grad_(True)
+    sdt = dict(sd)
+    sdt.update(leaves)
+    out = training_forward(sdt, x, qualities, noise_y, noise_z, single=single)
+    crit = scalable_rd_loss(out, x, lmbda)
+    crit["loss"].backward()
+    det = lambda t: t.detach() if torch.is_tensor(t) else t
+    return {"out": {k: ({kk: det(vv) for kk, vv in v.items()} if isinstance(v, dict) else det(v)) for k, v in out.items()},
+            "crit": {k: det(v) for k, v in crit.items()}, "grads": {k: v.grad for k, v in leaves.items()}}

@@ -293,3 +293,58 @@ def test_oracle_refine_gs_lrp_step_matches_reference():
         off += len(s_)
         assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
         assert np.abs(s_ - ref).max() <= 1e-5 * norm + 1e-12, name
+
+
+TRAIN_FIXTURES = (("first_train_step", [0, 10], [0.0055, 0.04], False), ("train_single_step", [2.5], 0.01, True))
+
+
+def train_fixture_inputs():
+    """Inputs of tests/golden/{first_train_step,train_single_step}.npz (oracle/gen_golden.py section 10)."""
+    return (synth.synth_image(2, 64, 64, seed=5), synth.uniform((2, 640, 4, 4), 201) - 0.5,
+            synth.uniform((2, 192, 1, 1), 202) - 0.5)
+
+
+@pytest.mark.parametrize("fixture,qualities,lmbda,single", TRAIN_FIXTURES)
+def test_oracle_first_train_step_matches_reference(fixture, qualities, lmbda, single):
+    """BASELINE configs[3] (`--training_type first_train`): the oracle's training forward (pic.py:301-491 / :497-666 with
+    training=True), ScalableRateDistortionLoss (training/loss.py:6-66) and autograd over EVERY parameter against the
+    reference's own step — loss terms, likelihoods, reconstructions, and all 1065 (965 for the single-quality pass, which
+    leaves g_s[0] unused) gradient tensors (norm + every 997th element)."""
+    import argparse
+    import warnings
+    import vampic
+    from conftest import README_ARGS
+    net = vampic.get_model(argparse.Namespace(model="pic", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    gold = np.load(os.path.join(GOLD, fixture + ".npz"))
+    x, ny, nz = train_fixture_inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single)
+    got = [float(r["crit"][k].mean()) for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype")]
+    for a, b in zip(got, gold["loss"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b))
+    _close(r["crit"]["mse_loss"], gold["mse"], 1e-6)
+    _close(r["out"]["likelihoods"]["y"], gold["lik_y"], 1e-5)
+    _close(r["out"]["likelihoods"]["z"], gold["lik_z"], 1e-5)
+    if single:
+        _close(r["out"]["x_hat"][:, :, ::4, ::4], gold["x_hat"], 2e-5)
+        _close(r["out"]["y_hat"], gold["y_hat"], 2e-5)
+    else:
+        _close(r["out"]["x_hat"][:, :, :, ::4, ::4], gold["x_hat"], 2e-5)
+        _close(r["out"]["likelihoods"]["y_prog"], gold["lik_y_prog"], 1e-5)
+        _close(r["out"]["y_base"], gold["y_hat_base"], 2e-5)
+        _close(r["out"]["y_prog"], gold["y_hat_prog"], 2e-5)
+    names = [str(n) for n in gold["grad_names"]]
+    assert sorted(k for k, g in r["grads"].items() if g is not None) == sorted(names)
+    assert len(names) == (965 if single else 1065)
+    off, num, den = 0, 0.0, 0.0
+    for name, norm in zip(names, gold["grad_norms"]):
+        g = r["grads"][name].reshape(-1)
+        s_ = g[::997].numpy()
+        ref = gold["grad_samples"][off:off + len(s_)]
+        off += len(s_)
+        assert abs(float(g.double().norm()) - norm) <= 2e-5 * norm + 1e-9, name
+        num += float(((s_ - ref).astype(np.float64) ** 2).sum())
+        den += float((ref.astype(np.float64) ** 2).sum())
+    assert (num / den) ** 0.5 <= 1e-5
