@@ -23,7 +23,7 @@ CONV_W_BF16, CONV_IN_BF16, CONV_OUT_BF16, CONV_AUX_BF16 = 32, 64, 128, 256      
 PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD, PACK_GDN_T = range(6)
 # enum vam_ew_op
 (EW_GELU_FWD, EW_GELU_BWD, EW_GATE_BWD, EW_GDN_APPLY, EW_GDN_BWD_PREP, EW_GDN_BWD_FIN, EW_CLAMP_BWD, EW_AXPY, EW_GATE_FWD,
- EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD) = range(12)
+ EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD, EW_MASK_SPLIT) = range(13)
 # enum vam_family
 FAM_CONV, FAM_ATTN, FAM_MASK, FAM_TAIL, FAM_MISC = range(5)
 FAMILY_NAMES = ("conv_igemm", "win_attn", "variance_mask", "gauss_tail", "misc")
@@ -120,6 +120,10 @@ _SIGNATURES = {
     "vam_train_elementwise": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
                               + [C.c_int] * 7 + [C.c_void_p]),
+    "vam_eb_train_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_long, C.c_void_p]),
+    "vam_ps2_unshuffle": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vam_upsample2_zero": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_rans_encode": (C.c_long, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "vam_rans_decode": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

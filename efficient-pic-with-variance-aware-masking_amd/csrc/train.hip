@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int H = pr.H, W = pr.W, HW = H * W;
-  const int stride = pr.stride == 2 ? 2 : 1;                       // 2: the k5/s2/p2 convolution (x is [B, Hx, Wx])
+  const int stride = pr.stride == 2 ? 2 : 1;                       // 2: a stride-2 / pad k/2 convolution (x is [B, Hx, Wx])
   const int Hx = stride == 2 ? pr.Hx : H, Wx = stride == 2 ? pr.Wx : W;
   const long HWx = (long)Hx * Wx;
   const long P = (long)pr.B * HW;
@@ -226,8 +226,8 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     const vam_wgrad& p = probs[i];
     VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
     VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (pad k/2)");
-    VAM_REQUIRE(p.stride == 0 || p.stride == 1 || (p.stride == 2 && p.kh == 5 && p.Hx == 2 * p.H && p.Wx == 2 * p.W),
-                "vam_conv_wgrad_group: problem %d: stride %d (1, or 2 with k5 and x of extent 2H x 2W)", i, p.stride);
+    VAM_REQUIRE(p.stride == 0 || p.stride == 1 || (p.stride == 2 && p.kh >= 3 && p.Hx == 2 * p.H && p.Wx == 2 * p.W),
+                "vam_conv_wgrad_group: problem %d: stride %d (1, or 2 with k3 / k5 and x of extent 2H x 2W)", i, p.stride);
     VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
     int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
     max_blocks = nb > max_blocks ? nb : max_blocks;

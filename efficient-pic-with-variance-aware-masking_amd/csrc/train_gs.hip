@@ -27,7 +27,7 @@ __device__ __forceinline__ float gelu_d(float v) {
 }
 
 enum { EW_GELU_FWD = 0, EW_GELU_BWD, EW_GATE_BWD, EW_GDN_APPLY, EW_GDN_BWD_PREP, EW_GDN_BWD_FIN, EW_CLAMP_BWD, EW_AXPY, EW_GATE_FWD,
-       EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD };
+       EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD, EW_MASK_SPLIT };
 
 template <int OP>
 __global__ void ew_kernel(const EwArgs a) {
@@ -109,6 +109,15 @@ __global__ void ew_kernel(const EwArgs a) {
         o0[k] = g[k] * (0.5f * (1.0f - t * t));
       }
       st4(0, o0);
+    } else if constexpr (OP == EW_MASK_SPLIT) {               // in0 = g, in1 = m: out0 = g * m, out1 = g * (1 - m)
+      float4 t1 = ld4(1);
+      const float m[4] = {t1.x, t1.y, t1.z, t1.w};
+      for (int k = 0; k < 4; ++k) {
+        o0[k] = x0[k] * m[k];
+        o1[k] = x0[k] * (1.0f - m[k]);
+      }
+      st4(0, o0);
+      st4(1, o1);
     } else if constexpr (OP == EW_REPARAM_BWD) {
       // NonNegativeParametrizer (compressai 1.2.4): value = max(p, bound)^2 - pedestal, LowerBound's gradient rule on the
       // max.  in0 = stored parameter p, in1 = dL/dvalue, coef = bound -> dL/dp
@@ -305,8 +314,8 @@ int vam_train_elementwise(int op, const vam_ew* e, void* stream) {
   a.n_vec = e->n_pix * (e->C / 4);
   a.coef = e->coef;
   a.flag = e->flag;
-  static const int n_in[] = {1, 2, 3, 2, 3, 3, 2, 2, 3, 2, 3, 2}, n_out[] = {1, 1, 2, 1, 3, 1, 1, 1, 1, 1, 1, 1};
-  VAM_REQUIRE(op >= 0 && op <= VAM_EW_HTANH_BWD, "vam_train_elementwise: op %d", op);
+  static const int n_in[] = {1, 2, 3, 2, 3, 3, 2, 2, 3, 2, 3, 2, 2}, n_out[] = {1, 1, 2, 1, 3, 1, 1, 1, 1, 1, 1, 1, 2};
+  VAM_REQUIRE(op >= 0 && op <= VAM_EW_MASK_SPLIT, "vam_train_elementwise: op %d", op);
   for (int k = 0; k < n_in[op]; ++k) VAM_REQUIRE(a.in[k], "vam_train_elementwise: op %d needs %d inputs", op, n_in[op]);
   for (int k = 0; k < n_out[op]; ++k) VAM_REQUIRE(a.out[k], "vam_train_elementwise: op %d needs %d outputs", op, n_out[op]);
   hipStream_t s = (hipStream_t)stream;
@@ -322,6 +331,7 @@ int vam_train_elementwise(int op, const vam_ew* e, void* stream) {
     case VAM_EW_REPARAM_BWD: return launch_ew<EW_REPARAM_BWD>(a, s);
     case VAM_EW_HTANH_FWD: return launch_ew<EW_HTANH_FWD>(a, s);
     case VAM_EW_HTANH_BWD: return launch_ew<EW_HTANH_BWD>(a, s);
+    case VAM_EW_MASK_SPLIT: return launch_ew<EW_MASK_SPLIT>(a, s);
     default: return launch_ew<EW_AXPY>(a, s);
   }
 }

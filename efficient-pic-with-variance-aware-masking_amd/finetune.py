@@ -204,3 +204,91 @@ def train_one_epoch_refine_gs(model, criterion, train_dataloader: Iterable[torch
         counter += 1
     n = max(n, 1)
     return counter, tot["loss"] / n, tot["bpp_loss"] / n, tot["mse_loss"] / n, tot["bpp_scalable"] / n
+
+
+# ============================================================================= first-stage training (--training_type first_train)
+class ScalableRateDistortionLoss(nn.Module):
+    """training/loss.py:6-66: loss = bpp_scalable + bpp_base + n_rec * bpp_hype + weight * mean(lmbda * mse per level).
+    Kept with the reference's own accounting: "y_prog" holds the base slices' likelihoods again, so the base rate enters
+    twice; ``n_rec`` = x_hat.shape[0] — the number of levels for the stacked output of ``forward``, the
+    number of images for a single-quality output."""
+
+    def __init__(self, weight=255 ** 2, lmbda_list=(0.005, 0.05), device="cuda"):
+        super().__init__()
+        self.scalable_levels = len(lmbda_list)
+        self.lmbda = torch.tensor(list(lmbda_list), dtype=torch.float32).to(device)
+        self.weight, self.device = weight, device
+
+    def forward(self, output, target, lmbda=None):
+        n_img, _, H, W = target.size()
+        n_rec = output["x_hat"].shape[0]
+        tgt = target.unsqueeze(0)
+        if n_rec != 1 and n_rec != n_img:
+            tgt = tgt.repeat(n_rec, 1, 1, 1, 1)
+        lm = self.lmbda if lmbda is None else torch.tensor([lmbda], dtype=torch.float32).to(self.device)
+        out = {"mse_loss": ((tgt - output["x_hat"]) ** 2).mean(dim=(1, 2, 3, 4))}       # one value per level
+        den = -math.log(2) * n_img * H * W
+        lik = output["likelihoods"]
+        out["bpp_hype"] = torch.log(lik["z"]).sum() / den
+        if "y_prog" in lik:
+            out["bpp_base"] = torch.log(lik["y"]).sum() / den
+            out["bpp_scalable"] = torch.log(lik["y_prog"]).sum() / den
+        else:
+            out["bpp_base"] = torch.log(lik["y"].squeeze(0)).sum() / den
+            out["bpp_scalable"] = torch.log(lik["y"]).sum() / den * 0.0
+        out["bpp_loss"] = out["bpp_scalable"] + out["bpp_base"] + n_rec * out["bpp_hype"]
+        out["loss"] = out["bpp_loss"] + self.weight * (lm * out["mse_loss"]).mean()
+        return out
+
+
+def first_train_setup(model):
+    """train.py:146-149 / :214-226: the first stage freezes nothing."""
+    for p in model.parameters():
+        p.requires_grad = True
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def first_train_step(model, criterion, batch: torch.Tensor, optimizer, list_quality: Sequence[float] = (0, 10),
+                     clip_max_norm: float = 1.0, noise=None, aux_optimizer=None) -> dict:
+    """One optimisation step of the first-stage schedule on this rank's shard (training/step.py:56-99 with
+    ``sampling_training=False``): ``out = model(d, quality=[0, 10])``, criterion, backward, clip, step.  On a multi-GPU
+    job the gradients are averaged over the ranks DURING ``backward()``: the plan's flat gradient buffer is cut into
+    ~25 MB buckets in the order the backward finishes them, and each bucket's all-reduce (RCCL) is issued on a
+    communication stream as soon as its last weight gradient has been enqueued (sharding.BucketReducer); the clip runs
+    after the last bucket, on the averaged gradients, so every rank applies the same scale."""
+    from . import sharding as S
+    optimizer.zero_grad()
+    if aux_optimizer is not None:
+        aux_optimizer.zero_grad()
+    if S.world_size() > 1 and getattr(model, "grad_reducer", None) is None:
+        model.grad_reducer = S.BucketReducer()
+    out = model(batch, quality=list(list_quality), training=True, noise=noise)
+    crit = criterion(out, batch)
+    crit["loss"].backward()
+    if aux_optimizer is not None:                      # training/step.py:91-94 (never taken by the reference: "first_strain")
+        aux = model.aux_loss()
+        aux.backward()
+        aux_optimizer.step()
+    if clip_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
+    optimizer.step()
+    return crit
+
+
+def train_one_epoch_first_train(model, criterion, train_dataloader: Iterable[torch.Tensor], optimizer, epoch: int, counter: int,
+                                list_quality: Sequence[float] = (0, 10), clip_max_norm: float = 1.0, aux_optimizer=None):
+    """``train_one_epoch(model, criterion, loader, optimizer, aux_optimizer, epoch, counter, sampling_training=False,
+    list_quality=[0, 10])`` of the reference (training/step.py:32-135).  Returns (counter, mean loss, mean bpp, mean mse,
+    mean scalable bpp)."""
+    model.train()
+    device = next(model.parameters()).device
+    tot = {"loss": 0.0, "bpp_loss": 0.0, "mse_loss": 0.0, "bpp_scalable": 0.0}
+    n = 0
+    for d in train_dataloader:
+        crit = first_train_step(model, criterion, d.to(device), optimizer, list_quality, clip_max_norm, aux_optimizer=aux_optimizer)
+        for k in tot:
+            tot[k] += float(crit[k].detach().mean())
+        n += 1
+        counter += 1
+    n = max(n, 1)
+    return counter, tot["loss"] / n, tot["bpp_loss"] / n, tot["mse_loss"] / n, tot["bpp_scalable"] / n

@@ -40,16 +40,87 @@ class TransformPacks:
         self.d: Dict[int, ops.Packed] = {}
         self._refresh = []
         self.keep = []
-        for m in stack.modules():
-            if isinstance(m, Ly.Conv2d):
-                assert m.stride == 1 and not m.is_rgb_s2d, "training lowering: stride-1 convolutions (synthesis transform)"
-                self._add_conv(m)
-            elif isinstance(m, Ly.Linear):
-                self._add_linear(m)
-            elif isinstance(m, Ly.ConvTranspose2d):
-                self._add_deconv(m)
-            elif isinstance(m, Ly.GDN):
-                self._add_gdn(m)
+        self._walk(stack)
+
+    def _walk(self, mod):
+        if isinstance(mod, Ly.SubpelConv):             # conv3x3 + PixelShuffle(2): a leaf (its inner Conv2d packs phase-major)
+            self._add_subpel(mod)
+        elif isinstance(mod, Ly.Conv2d):
+            if mod.is_rgb_s2d:
+                self._add_conv_rgb(mod)
+            elif mod.stride == 2:
+                self._add_conv_s2(mod)
+            else:
+                self._add_conv(mod)
+        elif isinstance(mod, Ly.Linear):
+            self._add_linear(mod)
+        elif isinstance(mod, Ly.ConvTranspose2d):
+            self._add_deconv(mod)
+        elif isinstance(mod, Ly.GDN):
+            self._add_gdn(mod)
+        else:
+            for ch in mod.children():
+                self._walk(ch)
+
+    # ---- first-stage training (analysis transforms, hyperprior): the remaining layer kinds
+    def _add_conv_s2(self, c):
+        """Stride-2 convolution (k5: g_a, layers/layers.py:5-12; k3: h_a, builder.py:72-82).  Data gradient of the k5 one =
+        the transposed convolution k5/s2/p2/op1 with the SAME tensor read as IOHW (I = Cout, O = Cin): four sub-pixel phase
+        problems; of the k3 one = VAM_PACK_CONV_DGRAD on the zero-inserted output gradient (vam_upsample2_zero)."""
+        n, cin, k = c.out_channels, c.in_channels, c.kernel_size
+        f = ops.pack_conv(c.weight, c.bias, 2)
+        if k == 5:
+            assert cin % 4 == 0
+            zb = torch.zeros(cin, dtype=torch.float32, device=c.weight.device)
+            d = ops.pack_deconv(c.weight, zb)
+            self.keep.append(zb)
+        else:
+            d = ops.pack_conv_dgrad(c.weight)
+        self.f[id(c)], self.d[id(c)] = f, d
+
+        def refresh():
+            ops.repack_weights(c.weight, f.w, L.PACK_CONV, 0, k, k, cin, n)
+            ops.repack_bias(c.bias, f.b, L.PACK_CONV, n)
+            if k == 5:
+                for ph, pk in enumerate(d):
+                    ops.repack_weights(c.weight, pk.w, L.PACK_DECONV5S2, ph, pk.kh, pk.kw, n, cin)
+            else:
+                ops.repack_weights(c.weight, d.w, L.PACK_CONV_DGRAD, 0, k, k, n, cin)
+        self._refresh.append(refresh)
+
+    def _add_conv_rgb(self, c):
+        """conv5x5 s2 (3 -> N) run as a 3x3 problem on the space-to-depth input (ops.pack_conv5s2_rgb): the re-indexed
+        16-channel weight tensor is rebuilt from the parameter at every refresh; the image has no data gradient."""
+        n = c.out_channels
+        w16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=c.weight.device)
+        w6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=c.weight.device)
+        self.keep += [w16, w6]
+
+        def gather():
+            w6[:, :, :5, :5].copy_(c.weight.detach())
+            w16[:, :12].copy_(w6.reshape(n, 3, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 12, 3, 3))
+        gather()
+        f = ops.Packed(ops.pack_weights(w16, L.PACK_CONV, 0, 3, 3, 16, n), ops.pack_bias(c.bias, L.PACK_CONV, n), 3, 3, 16, n, 1, 1, 1)
+        self.f[id(c)] = f
+
+        def refresh():
+            gather()
+            ops.repack_weights(w16, f.w, L.PACK_CONV, 0, 3, 3, 16, n)
+            ops.repack_bias(c.bias, f.b, L.PACK_CONV, n)
+        self._refresh.append(refresh)
+
+    def _add_subpel(self, m):
+        c = m[0]
+        n, cin = c.out_channels, c.in_channels
+        f = ops.pack_subpel(c.weight, c.bias)
+        d = ops.pack_conv_dgrad(c.weight)                # on the un-shuffled gradient, reference channel order
+        self.f[id(m)], self.d[id(m)] = f, d
+
+        def refresh():
+            ops.repack_weights(c.weight, f.w, L.PACK_PS2, 0, 3, 3, cin, n)
+            ops.repack_bias(c.bias, f.b, L.PACK_PS2, n)
+            ops.repack_weights(c.weight, d.w, L.PACK_CONV_DGRAD, 0, 3, 3, n, cin)
+        self._refresh.append(refresh)
 
     def _add_conv(self, c):
         n, cin, k = c.out_channels, c.in_channels, c.kernel_size
@@ -142,8 +213,8 @@ def _ru_fwd(plan, pk: TransformPacks, ru: Ly.ResidualUnit, x: View, tape: list) 
     return o
 
 
-def _attention_block_fwd(plan, pk, blk: Ly.Win_noShift_Attention, x: View, tape: list) -> View:
-    """a * sigmoid(b) + x  (layers/layers.py:50-74)."""
+def _attention_block_fwd(plan, pk, blk: Ly.Win_noShift_Attention, x: View, tape: list, out: Optional[View] = None) -> View:
+    """a * sigmoid(b) + x  (layers/layers.py:50-74); ``out``: write the result into this window."""
     rec = dict(kind="attn", mod=blk, x=x, a_tape=[], b_tape=[])
     wa = blk.conv_b[0]
     qkv = plan.buf(x.B, x.H, x.W, 3 * x.C)
@@ -161,7 +232,7 @@ def _attention_block_fwd(plan, pk, blk: Ly.Win_noShift_Attention, x: View, tape:
     a = x
     for i in range(3):
         a = _ru_fwd(plan, pk, blk.conv_a[i], a, rec["a_tape"])
-    out = plan.buf(x.B, x.H, x.W, x.C)
+    out = out if out is not None else plan.buf(x.B, x.H, x.W, x.C)
     plan.call(lambda: ops.ew(L.EW_GATE_FWD, [a, b4p, x], [out]), "gate")
     rec.update(a=a, b3=b, b4p=b4p)
     tape.append(rec)
@@ -185,8 +256,9 @@ def _gdn_fwd(plan, pk, g: Ly.GDN, x: View, tape: list) -> View:
     return y
 
 
-def lower_g_s_train(plan: E.Plan, dec: nn.Sequential, y: View, x_hat: torch.Tensor, pk: TransformPacks) -> list:
-    """models/builder.py:8-18 + clamp_(0, 1) (pic.py:651), keeping the tape.  Values equal engine.lower_g_s."""
+def lower_g_s_train(plan: E.Plan, dec: nn.Sequential, y: View, x_hat: torch.Tensor, pk: TransformPacks, clamp: bool = True) -> list:
+    """models/builder.py:8-18 + clamp_(0, 1) (pic.py:651; ``forward`` of pic.py:372,462 does not clamp), keeping the tape.
+    Values equal engine.lower_g_s."""
     tape: list = []
     t = _attention_block_fwd(plan, pk, dec[0], y, tape)
     t = _deconv_fwd(plan, pk, dec[1], t, tape)
@@ -196,7 +268,7 @@ def lower_g_s_train(plan: E.Plan, dec: nn.Sequential, y: View, x_hat: torch.Tens
     t = _attention_block_fwd(plan, pk, dec[5], t, tape)
     t = _deconv_fwd(plan, pk, dec[6], t, tape)
     t = _gdn_fwd(plan, pk, dec[7], t, tape)
-    _deconv_fwd(plan, pk, dec[8], t, tape, out_nchw=x_hat, act=L.ACT_CLAMP01)
+    _deconv_fwd(plan, pk, dec[8], t, tape, out_nchw=x_hat, act=L.ACT_CLAMP01 if clamp else L.ACT_NONE)
     return tape
 
 
@@ -298,7 +370,7 @@ def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
 
 
 def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torch.Tensor, pk: TransformPacks, grads,
-                       need_input_grad: bool = False) -> Optional[View]:
+                       need_input_grad: bool = False, clamp: bool = True) -> Optional[View]:
     """dL/d(parameters of the transform) from dL/dx_hat (NCHW, ``g_xhat``).  Nothing upstream of the transform's input is
     trainable under plain ``refine_gs`` (train.py:216-218); with ``--lrp`` the latent-residual-prediction stacks are
     (models/pic.py:171-184), and ``need_input_grad`` returns dL/dy_hat for them."""
@@ -306,9 +378,13 @@ def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torc
     gcl = torch.zeros_like(x_hat)
     d16 = bw.buf(B, H, W, 16, zero=True)
     bw.keep.append(gcl)
-    bw.call(lambda: (ops.ew(L.EW_CLAMP_BWD, [ops.flat_view(x_hat), ops.flat_view(g_xhat)], [ops.flat_view(gcl)]),
-                     L.check(L.load().vam_nchw_to_nhwc(gcl.data_ptr(), d16.ptr, B, 3, H, W, d16.ld, ops.stream_ptr()), "vam_nchw_to_nhwc")),
-            "clamp backward + NCHW -> NHWC")
+    if clamp:
+        bw.call(lambda: (ops.ew(L.EW_CLAMP_BWD, [ops.flat_view(x_hat), ops.flat_view(g_xhat)], [ops.flat_view(gcl)]),
+                         L.check(L.load().vam_nchw_to_nhwc(gcl.data_ptr(), d16.ptr, B, 3, H, W, d16.ld, ops.stream_ptr()), "vam_nchw_to_nhwc")),
+                "clamp backward + NCHW -> NHWC")
+    else:
+        bw.call(lambda: L.check(L.load().vam_nchw_to_nhwc(g_xhat.data_ptr(), d16.ptr, B, 3, H, W, d16.ld, ops.stream_ptr()), "vam_nchw_to_nhwc"),
+                "NCHW -> NHWC")
     d: Optional[View] = d16
     for i, r in enumerate(reversed(tape)):
         first = i == len(tape) - 1

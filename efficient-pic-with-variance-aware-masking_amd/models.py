@@ -330,13 +330,11 @@ class VarianceMaskingPIC(CompressionModel):
             other = [n for n, p in self.named_parameters()
                      if p.requires_grad and not n.startswith("post_latent.") and id(p) not in dec_ids and id(p) not in lrp_ids]
             n_lrp = sum(p.requires_grad for p in lrp_ps)
-            if other or not self.all_scalable or (n_lrp and (quality == 0 or n_lrp != len(lrp_ps))):
-                raise NotImplementedError("backward kernels exist for the synthesis transform and the progressive LRP stacks "
-                                          "(refine_gs: freeze_all(); unfreeze_decoder(lrp=...)) and for the REMs; gradients "
-                                          "of g_a / hyperprior / entropy-parameter stacks (SURVEY K14) are not built yet — "
-                                          f"trainable outside: {other[:3]}")
-            if not any(p.requires_grad for p in self._decoder_in_use(quality == 0).parameters()):
-                raise NotImplementedError("LRP stacks trainable without the synthesis transform: not a schedule of the reference")
+            if other or not self.all_scalable or (n_lrp and (quality == 0 or n_lrp != len(lrp_ps))) or \
+                    not any(p.requires_grad for p in self._decoder_in_use(quality == 0).parameters()):
+                # anything beyond the decoder-refinement subsets (first_train: everything; refine_gs_ga: g_s[1] + g_a[1],
+                # train.py:219-222): the complete training plan (full_train.py)
+                return self._forward_full_train(x, [quality], mask_pol, noise, single=True)
             train_gs, train_lrp = True, bool(n_lrp)
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
@@ -348,12 +346,13 @@ class VarianceMaskingPIC(CompressionModel):
         if mask_pol == "two-levels" and quality != 0:
             pr = 10                                   # channel_mask.py:152-153: all ones unless pr == 0
         nb = _max_images_per_plan(x)
+        if train_gs and x.shape[0] > nb:                # one tape per plan: sub-batches would overwrite each other's
+            raise NotImplementedError(f"training with gradients: at most {nb} images of {x.shape[2]}x{x.shape[3]} per step "
+                                      "(one plan's 32-bit addressing range); split the batch and accumulate")
         if x.shape[0] > nb:                            # tensors of one plan are addressed with 32-bit byte offsets
             sub = lambda i: None if noise is None else {k: v[i:i + nb] for k, v in noise.items()}
             return _cat_outputs([self.forward_single_quality(x[i:i + nb], quality, mask_pol, training, True, sub(i))
                                  for i in range(0, x.shape[0], nb)])
-        if train_gs and x.shape[0] > nb:
-            raise NotImplementedError("refine_gs training: batch larger than one plan's 32-bit addressing range")
         plan = self._plan(x.detach(), base_only=(quality == 0), train=bool(training), train_gs=train_gs, train_lrp=train_lrp)
         out = plan.execute(x.detach(), pr, None, self.use_graph, clone, noise=noise)
         if train_gs:
@@ -366,6 +365,8 @@ class VarianceMaskingPIC(CompressionModel):
         (values only, see :meth:`forward_single_quality`); the same noise tensors serve every quality, as one
         ``uniform_`` draw per slice would in a single reference pass."""
         qs = self.define_quality(quality)
+        if training and torch.is_grad_enabled() and self._trainable_outside_rem():
+            return self._forward_full_train(x, qs, mask_pol, noise, single=False)
         base = self.forward_single_quality(x, 0, mask_pol, training, noise=noise)
         x_hats, y_prog, y_hat_total = [base["x_hat"].unsqueeze(0)], [], [base["y_hat"]]
         out = None
@@ -379,6 +380,49 @@ class VarianceMaskingPIC(CompressionModel):
                 "likelihoods": {"y": lik_b, "y_prog": torch.cat(y_prog, 0) if y_prog else lik_b,
                                 "z": base["likelihoods"]["z"]},
                 "y_hat": y_hat_total, "y_base": base["y_hat"], "y_prog": out["y_hat"] if out else base["y_hat"]}
+
+    def _forward_full_train(self, x, qs, mask_pol, noise, single: bool):
+        """Training forward WITH gradients of every trainable parameter (BASELINE configs[3] `first_train`, train.py:146-149;
+        `refine_gs_ga` as a subset): full_train.FullTrainPlan, autograd-connected through :class:`_FullTrainFn`.
+        ``single`` = False: ``forward(x, [0, q])`` (pic.py:301-491); True: ``forward_single_quality(x, q)`` (:497-666)."""
+        from .full_train import FullTrainPlan
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in ("point-based-std", "two-levels"):
+            raise NotImplementedError()
+        if not single and (len(qs) != 2 or qs[0] != 0 or qs[1] == 0):
+            raise NotImplementedError("training forward with gradients: quality lists [0, q] (train.py:147: [0, 10]); "
+                                      f"got {qs}")
+        Ly._no_autograd(x)
+        L.require_gpu()
+        self._check_config()
+        q = qs[-1]
+        nb = _max_images_per_plan(x)
+        if x.shape[0] > nb:
+            raise NotImplementedError(f"training with gradients: at most {nb} images of {x.shape[2]}x{x.shape[3]} per step")
+        B, C_, H, W = x.shape
+        if C_ != 3 or H % 64 or W % 64:
+            raise ValueError(f"expected [B,3,H,W] with H,W multiples of 64 (reference pads to 64), got {tuple(x.shape)}")
+        base_only = single and q == 0
+        key = ("full_train", B, H, W, "single" if single else "multi", base_only, str(x.device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = FullTrainPlan(self, B, H, W, "single" if single else "multi", base_only, x.device)
+            self._plans[key] = plan
+        pr = 10 if (mask_pol == "two-levels" and q != 0) else q
+        raw = plan.execute(x.detach(), pr, self.use_graph, noise=noise)
+        x_hat, lik, z_lik = _FullTrainFn.apply(plan, self.use_graph, getattr(self, "grad_reducer", None), raw["x_hat"], raw["lik"],
+                                               raw["z_lik"], *plan.params)
+        d = self.division_dimension[0]
+        if single:
+            yh = raw["y_base"] if base_only else raw["y_prog"]
+            out = {"x_hat": x_hat[0], "likelihoods": {"y": lik, "z": z_lik}, "y_hat": yh, "y_base": raw["y_base"], "y_prog": yh,
+                   "mu_base": raw["mu_base"], "std_base": raw["std_base"]}
+            if not base_only:
+                out.update({"mu": raw["mu"], "std": raw["std"], "mask": raw["mask"]})
+            return out
+        return {"x_hat": x_hat, "likelihoods": {"y": lik[:, :d], "y_prog": lik.unsqueeze(0), "z": z_lik},   # pic.py:389-390,471-472,486-491
+                "y_hat": [raw["y_base"], raw["y_prog"]], "y_base": raw["y_base"], "y_prog": raw["y_prog"],
+                "mu_base": raw["mu_base"], "std_base": raw["std_base"], "mu_prog": raw["mu"], "std_prog": raw["std"]}
 
     # ---- bitstream path (models/pic.py:671-967; rem_pic.py:425-818)
     def _rem_choice(self, quality, checkpoint_rep):
@@ -735,6 +779,26 @@ class _GsTrainFn(torch.autograd.Function):
                                "the later forward — call loss.backward() before the next training forward of this shape")
         grads = ctx.plan.backward_gs(g.contiguous(), ctx.use_graph)
         return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
+class _FullTrainFn(torch.autograd.Function):
+    """(x_hat, likelihoods y, likelihoods z) of the complete training plan as differentiable functions of every parameter
+    on the path.  backward() runs the plan's backward (and, when the model carries a ``grad_reducer``, the bucketed
+    gradient exchange of a multi-GPU job while it runs) and hands each parameter its slice of the flat buffer."""
+
+    @staticmethod
+    def forward(ctx, plan, use_graph, reducer, x_hat, lik, z_lik, *params):
+        ctx.plan, ctx.use_graph, ctx.reducer, ctx.generation = plan, use_graph, reducer, plan.generation
+        return x_hat, lik, z_lik
+
+    @staticmethod
+    def backward(ctx, g_xhat, g_lik, g_z):
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError("the training plan for this shape ran again before this backward(): its tape now belongs to "
+                               "the later forward — call loss.backward() before the next training forward of this shape")
+        views = ctx.plan.backward(g_xhat, g_lik, g_z, ctx.use_graph, ctx.reducer)
+        need = ctx.needs_input_grad[6:]
+        return (None,) * 6 + tuple(v.clone() if n else None for v, n in zip(views, need))
 
 
 class _FsqPlan:

@@ -547,6 +547,25 @@ def repack_bias(src: torch.Tensor, dst: torch.Tensor, mode: int, n: int):
     L.check(L.load().vam_pack_bias(src.data_ptr(), dst.data_ptr(), mode, n, stream_ptr()), "vam_pack_bias")
 
 
+def eb_train_bwd(z: View, noise: View, params: torch.Tensor, grad_lik: View, dz: View, dparams: torch.Tensor):
+    """Backward of the training-mode entropy bottleneck (vam_eb_train_bwd): dz written, dparams in ``params`` layout."""
+    assert dparams.numel() == params.numel() and dparams.is_contiguous()
+    L.check(L.load().vam_eb_train_bwd(z.ptr, z.ld, noise.ptr, noise.ld, params.data_ptr(), z.C, grad_lik.ptr, grad_lik.ld,
+                                      dz.ptr, dz.ld, dparams.data_ptr(), z.n_pix, stream_ptr()), "vam_eb_train_bwd")
+
+
+def ps2_unshuffle(src: View, dst: View):
+    """Gradient of PixelShuffle(2): src [B,2H,2W,Cq] -> dst [B,H,W,4Cq] in the convolution's channel order c*4+i*2+j."""
+    assert src.C * 4 == dst.C and (src.H, src.W) == (2 * dst.H, 2 * dst.W) and src.B == dst.B
+    L.check(L.load().vam_ps2_unshuffle(src.ptr, src.ld, dst.ptr, dst.ld, dst.B, dst.H, dst.W, src.C, stream_ptr()), "vam_ps2_unshuffle")
+
+
+def upsample2_zero(src: View, dst: View):
+    """dst[b,2y,2x] = src[b,y,x], zeros elsewhere (data gradient of a stride-2 3x3 convolution, first half)."""
+    assert src.C == dst.C and (dst.H, dst.W) == (2 * src.H, 2 * src.W) and src.B == dst.B
+    L.check(L.load().vam_upsample2_zero(src.ptr, src.ld, dst.ptr, dst.ld, src.B, src.H, src.W, src.C, stream_ptr()), "vam_upsample2_zero")
+
+
 def memset_zero(t: torch.Tensor):
     L.check(L.load().vam_memset_zero(t.data_ptr(), t.numel() * t.element_size(), stream_ptr()), "vam_memset_zero")
 

@@ -94,3 +94,51 @@ def broadcast_choice(n_choices: int, rng, device="cpu") -> int:
     t = torch.tensor([idx], dtype=torch.int64, device=device)
     dist.broadcast(t, src=0)
     return int(t.item())
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class BucketReducer:
+    """Gradient exchange of first-stage training (BASELINE configs[3]: "RCCL grad all-reduce over xGMI"): the
+    backward plan calls this object with (bucket index, slice of its flat gradient buffer, stream the backward runs on)
+    each time a bucket is final; the all-reduce of that bucket is issued on a communication stream behind an event of
+    the backward's stream, so it overlaps the rest of the backward.  ``finish`` joins the collectives into the backward's
+    stream and divides by the world size (mean over ranks = the single-process gradient of the global batch, since the
+    loss is normalised by the LOCAL pixel count, training/loss.py:21,45).  Buckets are few and large (~25 MB): on the
+    xGMI mesh a ring is bound by one link, so large messages beat many small ones.  The layout is rank-invariant by
+    construction: every rank builds the same plan over the same parameter order, and a training forward uses every
+    parameter of the path.  ``log`` keeps (bucket index, elements) in issue order (tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.comm = None
+        self.pending: list = []
+        self.log: list = []
+
+    def __call__(self, idx: int, flat_slice: torch.Tensor, stream=None):
+        import torch.distributed as dist
+        self.log.append((idx, flat_slice.numel()))
+        if world_size() == 1:
+            return
+        if flat_slice.is_cuda:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=flat_slice.device)
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream(flat_slice.device))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                work = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat_slice))
+
+    def finish(self, stream=None):
+        """Order the caller's stream after every pending collective and turn the sums into means."""
+        w = world_size()
+        for work, sl in self.pending:
+            work.wait()                      # NCCL: the CURRENT stream waits for the collective; gloo: the host does
+            sl.div_(w)
+        self.pending = []

@@ -272,9 +272,9 @@ typedef struct vam_wgrad {
   int kh, kw;
   int C, N;
   int cin_total, c_off;
-  int stride;         /* 0 or 1: stride 1, pad k/2, x has the extent of dy.  2: the k5/s2/p2 convolution — x is   */
-  int Hx, Wx;         /* [B, Hx, Wx] (Hx = 2H, Wx = 2W): input pixel = 2*o - 2 + tap.  Used for the transposed     */
-                      /* convolutions of g_s, whose weight gradient is this with the roles of x and dy exchanged    */
+  int stride;         /* 0 or 1: stride 1, pad k/2, x has the extent of dy.  2: a stride-2, pad k/2 convolution (k5: g_a,  */
+  int Hx, Wx;         /* k3: h_a) — x is [B, Hx, Wx] (Hx = 2H, Wx = 2W): input pixel = 2*o - k/2 + tap.  Also the   */
+                      /* transposed convolutions of g_s: their weight gradient is this with x and dy exchanged      */
 } vam_wgrad;
 int vam_conv_wgrad_group(const vam_wgrad* problems, int n_problems, void* stream);
 int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw,
@@ -308,7 +308,9 @@ enum vam_ew_op {
   VAM_EW_GATE_FWD = 8,      /* in0 = a, in1 = b, in2 = x: out0 = a*sigmoid(b) + x                                      */
   VAM_EW_REPARAM_BWD = 9,   /* NonNegativeParametrizer backward: in0 = stored parameter, in1 = dL/dvalue, coef = bound */
   VAM_EW_HTANH_FWD = 10,    /* LRP tail (pic.py:635-641): in0 = z, in1 = quantised residual, in2 = base: (0.5 tanh z + in1) + in2 */
-  VAM_EW_HTANH_BWD = 11     /* in0 = z, in1 = dy: out0 = dy * 0.5 (1 - tanh(z)^2)                                         */
+  VAM_EW_HTANH_BWD = 11,    /* in0 = z, in1 = dy: out0 = dy * 0.5 (1 - tanh(z)^2)                                         */
+  VAM_EW_MASK_SPLIT = 12    /* straight-through rounding under the variance mask (pic.py:443: ste_round(r - mu) * m + mu):
+                               in0 = dL/d(result), in1 = m: out0 = in0 * m (to r), out1 = in0 * (1 - m) (to mu)           */
 };
 typedef struct vam_ew {
   vam_aux in[4];
@@ -325,6 +327,19 @@ int vam_train_elementwise(int op, const vam_ew* e, void* stream);
 int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int ld_do, float* dqkv, int ld_dq,
                           const float* table, float* dtable, int B, int H, int W, int C, int heads, int ws, int shift,
                           void* stream);
+
+/* ------------------------------------------------------------------ first-stage training (configs[3]) */
+/* Backward of the training-mode entropy bottleneck (entropy_models.py:403-436,449-492 with quantize "noise"): for
+ * lik = max(|sigmoid(s u) - sigmoid(s l)|, 1e-9), u / l = logits_cumulative(z + noise +/- 0.5), s = -sign(l + u) detached:
+ * dz = grad_lik * dlik/dz (written, not accumulated) and dparams (layout of `params`, see vam_eb_forward; the quantiles'
+ * entries are zero: the noise likelihood does not read them) = sum over pixels, fixed order.  LowerBound rule on 1e-9. */
+int vam_eb_train_bwd(const float* z, int ld_z, const float* noise, int ld_noise, const float* params, int C,
+                     const float* grad_lik, int ld_glik, float* dz, int ld_dz, float* dparams, long n_pix, void* stream);
+/* Gradient of PixelShuffle(2) (layers/layers.py:82-86): dst[b,y,x,c*4+i*2+j] = src[b,2y+i,2x+j,c]; H, W = extent of dst. */
+int vam_ps2_unshuffle(const float* src, int ld_src, float* dst, int ld_dst, int B, int H, int W, int Cq, void* stream);
+/* dst[b,2y,2x,:] = src[b,y,x,:], zeros elsewhere (H, W = extent of src): with the VAM_PACK_CONV_DGRAD problem on dst this is
+ * the data gradient of a k3 / stride-2 / pad-1 convolution (h_a, models/builder.py:72-82). */
+int vam_upsample2_zero(const float* src, int ld_src, float* dst, int ld_dst, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------ bitstream (HOST pointers) */
 /* compressai `_CXX.pmf_to_quantized_cdf` (reference entropy_models.py:61-64): n probabilities ->

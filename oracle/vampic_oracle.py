@@ -735,14 +735,25 @@ def ste_round(x: Tensor) -> Tensor:
     return torch.round(x) - x.detach() + x
 
 
+def _ste_forced(x: Tensor, q: Optional[Tensor]) -> Tensor:
+    """ste_round with the rounding DECISION supplied (teacher forcing for parity tests: a latent within fp32 summation
+    noise of x.5 may round the other way on another back end, and every later slice is conditioned on it)."""
+    return ste_round(x) if q is None else q - x.detach() + x
+
+
 def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, *,
                      single: bool = False, div: int = 320, chunk: int = 32, max_support: int = 5,
-                     prog_support: int = 5) -> dict:
+                     prog_support: int = 5, force: Optional[dict] = None) -> dict:
     """Training-mode forward, README flags (dual encoder / decoder / hyperprior, delta_encode, total_mu_rep,
     all_scalable).  ``single`` = False: ``forward(x, quality=[0, q])`` — both decoders, no clamp, likelihoods
     {"y": base, "y_prog": [1, B, 640] = base AND progressive (pic.py:389-390,471-472), "z"}.  ``single`` = True:
     ``forward_single_quality(x, q)`` — the decoder in use, ``clamp_(0, 1)``, likelihoods {"y", "z"}.  ``noise_y`` [B,640,h,w]
-    / ``noise_z`` [B,192,h/4,w/4]: the U(-.5,.5) draws of quantize("noise") (entropy_models.py:132-138)."""
+    / ``noise_z`` [B,192,h/4,w/4]: the U(-.5,.5) draws of quantize("noise") (entropy_models.py:132-138).
+    ``force`` (tests only) = {"base_sym", "prog_sym": round(y - mu) [B,320,h,w], "mask": [B,320,h,w], "z_sym"}: the hard
+    decisions of another run of the same step, imposed instead of recomputed (values AND gradients then agree to
+    rounding noise; without it this is the reference's arithmetic, pinned by tests/golden/first_train_step.npz)."""
+    force = force or {}
+    fsl = lambda key, j: force[key][:, j * chunk:(j + 1) * chunk] if key in force else None
     qs = list(qualities)
     assert (single and len(qs) == 1) or (not single and len(qs) == 2 and qs[0] == 0)
     q = qs[-1]
@@ -751,7 +762,7 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
     z = h_a(sd, y)                                                                       # :280
     z_lik = eb_likelihood_noise_bounded(sd, z, noise_z)
     med = sd["entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
-    z_hat = ste_round(z - med) + med                                                     # :282-284
+    z_hat = _ste_forced(z - med, force.get("z_sym")) + med                               # :282-284
     if base_only:                                                                        # :285-288 (quality == 0)
         means_h, scales_h = h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_scale_s.0.", z_hat)
     else:
@@ -770,7 +781,7 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
         mu_b.append(mu)
         std_b.append(sc)
         lik_b.append(gaussian_likelihood_noise(ys[i], sc, mu, nys[i]))
-        yh = ste_round(ys[i] - mu) + mu
+        yh = _ste_forced(ys[i] - mu, fsl("base_sym", i)) + mu
         lrp = cc_stack(sd, f"lrp_transforms.{i}.", torch.cat([msup, yh], 1))
         yhat_b.append(yh + 0.5 * torch.tanh(lrp))
     y_base = torch.cat(yhat_b, 1)
@@ -795,10 +806,10 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
         std_tot.append(sc)
         mu_p.append(mu)
         std_p.append(sc)
-        m = variance_mask(sc.detach(), q)                                                # hard comparison: no gradient (channel_mask.py:132-151)
+        m = variance_mask(sc.detach(), q) if "mask" not in force else fsl("mask", j)     # hard comparison: no gradient (channel_mask.py:132-151)
         masks.append(m)
         lik_p.append(gaussian_likelihood_noise((r - mu) * m, sc * m, None, nys[ns0 + j]))
-        rh = ste_round(r - mu) * m + mu                                                  # :443
+        rh = _ste_forced(r - mu, fsl("prog_sym", j)) * m + mu                            # :443
         lrp = cc_stack(sd, f"lrp_transforms_prog.{j}.", torch.cat([msup, rh], 1))
         yhat_p.append(rh + 0.5 * torch.tanh(lrp) + yhat_b[j])
     y_prog = torch.cat(yhat_p, 1)
@@ -853,7 +864,7 @@ def scalable_rd_loss(out: dict, target: Tensor, lmbda, weight: float = 255.0 ** 
 
 
 def first_train_step(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, lmbda, *,
-                     single: bool = False, trainable=None) -> dict:
+                     single: bool = False, trainable=None, force: Optional[dict] = None) -> dict:
     """One optimisation step's forward + backward with every floating-point parameter trainable (``trainable``: a
     predicate on the key name; default all).  Returns the forward outputs (detached), the loss terms and
     {name: gradient} — None where autograd left no gradient (a parameter the pass does not use)."""
@@ -867,7 +878,7 @@ def first_train_step(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
             leaves[k] = v.detach().clone().requires_grad_(True)
     sdt = dict(sd)
     sdt.update(leaves)
-    out = training_forward(sdt, x, qualities, noise_y, noise_z, single=single)
+    out = training_forward(sdt, x, qualities, noise_y, noise_z, single=single, force=force)
     crit = scalable_rd_loss(out, x, lmbda)
     crit["loss"].backward()
     det = lambda t: t.detach() if torch.is_tensor(t) else t
