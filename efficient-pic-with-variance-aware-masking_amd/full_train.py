@@ -503,22 +503,10 @@ class FullTrainPlan:
             lower_g_a_backward(bw, self.t_ga[k], D_y.window(k * d, d), pk(e), grads)
             done(e)
         # ------------------------------------------------------------------ buckets
-        self.bucket_bounds: List[tuple] = []         # (first element, one past the last) of the flat buffer
-        self.bucket_ready: List[int] = []            # backward-plan step after which the bucket is final
-        lo, ready = 0, 0
-        for o, p in zip(offs, order):
-            end = o + (p.numel() + 3) // 4 * 4
-            ready = max(ready, self.param_done[id(p)])
-            if (end - lo) * 4 >= BUCKET_BYTES:
-                self.bucket_bounds.append((lo, end))
-                self.bucket_ready.append(ready)
-                lo = end
-        if lo < tot:
-            self.bucket_bounds.append((lo, tot))
-            self.bucket_ready.append(len(bw.steps))
-        for i in range(1, len(self.bucket_ready)):                                    # monotone: a bucket is sent after its predecessors
-            self.bucket_ready[i] = max(self.bucket_ready[i], self.bucket_ready[i - 1])
-        self.bucket_ready[-1] = len(bw.steps)
+        from .sharding import bucket_partition
+        self.bucket_bounds, self.bucket_ready = bucket_partition(offs, [p.numel() for p in order],
+                                                                 [self.param_done[id(p)] for p in order], tot, len(bw.steps),
+                                                                 BUCKET_BYTES)
 
     # ------------------------------------------------------------------------------------------- execution
     def _own_stream(self):

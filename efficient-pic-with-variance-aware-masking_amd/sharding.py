@@ -101,6 +101,30 @@ def world_size() -> int:
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def bucket_partition(offsets, numels, done_steps, total: int, n_steps: int, bucket_bytes: int):
+    """Cut a flat fp32 gradient buffer (parameter k at ``offsets[k]``, 16-byte aligned, laid out in the order the backward
+    FINISHES the parameters) into buckets of at least ``bucket_bytes``: returns (bounds [(first element, one past the
+    last)], ready [index of the backward-plan step after which the bucket is final]).  ``ready`` is monotone — a bucket is
+    sent after its predecessors — and the last bucket closes with the plan.  Pure arithmetic on the plan's layout, hence
+    identical on every rank."""
+    bounds, ready = [], []
+    lo, r = 0, 0
+    for o, n, dn in zip(offsets, numels, done_steps):
+        end = o + (n + 3) // 4 * 4
+        r = max(r, dn)
+        if (end - lo) * 4 >= bucket_bytes:
+            bounds.append((lo, end))
+            ready.append(r)
+            lo = end
+    if lo < total:
+        bounds.append((lo, total))
+        ready.append(n_steps)
+    for i in range(1, len(ready)):
+        ready[i] = max(ready[i], ready[i - 1])
+    ready[-1] = n_steps
+    return bounds, ready
+
+
 class BucketReducer:
     """Gradient exchange of first-stage training (BASELINE configs[3]: "RCCL grad all-reduce over xGMI"): the
     backward plan calls this object with (bucket index, slice of its flat gradient buffer, stream the backward runs on)

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: first-stage training step (BASELINE.json configs[3]: `train.py first_train`, synthetic 256x256,
+batch 256 sharded over 8 MI355X = 32 images per GPU, RCCL gradient all-reduce over xGMI).
+
+A step = what training/step.py:56-99 does per batch with ``sampling_training=False``: zero_grad, ``model(d, quality=[0, 10])``
+(training forward, both decoders), ScalableRateDistortionLoss, backward of EVERY parameter (150 M, HIP kernels), the
+bucketed gradient all-reduce issued DURING the backward (~25 MB buckets in the order the backward finishes them; clip after
+the last bucket), clip_grad_norm_ 1.0, Adam.  One process per GPU; launched like bench.py:
+
+    python scripts/bench_train.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        scripts/bench_train.py --gpus N ...
+
+Prints one JSON line: whole-job images/s (weak scaling), the per-phase split and the algorithmic TFLOP/s of the step
+(138.14 GFLOP forward per 256x256 image at [0, 10], x3 with the backward: SURVEY 8d).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FWD_GFLOP_PER_IMAGE_256 = 138.14          # SURVEY 8d, forward([0, 10]) on one 256x256 image
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: start the ranks as children (bench.py)
+        from bench import self_launch
+        sys.exit(self_launch(sys.argv[1:], a.gpus, script=__file__))
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("VAMPIC_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            torch.cuda.set_device(local % ndev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
+    assert world == a.gpus and torch.cuda.is_available()
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    import vampic
+    from vampic import finetune as ft, sharding
+    from vampic.checkpoint import configure_optimizers
+    args = argparse.Namespace(model="pic", N=192, M=640, multiple_decoder=True, multiple_encoder=True,
+                              multiple_hyperprior=True, dim_chunk=32, division_dimension=[320, 640],
+                              mask_policy="point-based-std", support_progressive_slices=5, delta_encode=True,
+                              total_mu_rep=True, all_scalable=True, learning_rate=1e-4, aux_learning_rate=1e-3,
+                              training_type="first_train")
+    net = vampic.get_model(args, "cpu")
+    torch.nn.Module.load_state_dict(net, vampic.synth.synth_state_dict(net.state_dict(), seed=0))
+    net = net.to(dev).train()
+    ft.first_train_setup(net)
+    net.use_graph = not a.no_graph
+    opt, _ = configure_optimizers(net, args)
+    crit = ft.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device=dev)
+    x = vampic.synth.synth_image(a.batch, a.size, a.size, seed=300 + rank).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(a.warmup, 1)):
+        c = ft.first_train_step(net, crit, x, opt, [0, 10])
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        c = ft.first_train_step(net, crit, x, opt, [0, 10])
+    sync()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(dev)
+        return r, (time.perf_counter() - t) * 1e3
+    opt.zero_grad()
+    out, t_fwd = timed(lambda: net(x, quality=[0, 10], training=True))
+    loss = crit(out, x)["loss"]
+    _, t_bwd = timed(loss.backward)                         # includes the bucketed all-reduce when world > 1
+    _, t_opt = timed(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0), opt.step()))
+    if rank == 0:
+        plan = next(p for k, p in net._plans.items() if k[0] == "full_train")
+        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+        gflop = 3.0 * FWD_GFLOP_PER_IMAGE_256 * (a.size * a.size / 65536.0) * a.batch
+        print(json.dumps({"metric": "first_train images/sec (256x256 patches, forward [0,10] + backward of 150 M parameters + Adam)",
+                          "value": round(world * a.batch * a.steps / dt, 2), "unit": "images/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 split operands; weight gradients on the fp32 matrix pipe)",
+                          "data": "synthetic",
+                          "config": {"workload": f"first_train step, quality [0, 10], {a.batch}x3x{a.size}x{a.size} per GPU",
+                                     "global_batch": a.batch * world, "trainable_params": n_par, "grad_bytes": 4 * n_par,
+                                     "grad_buckets": len(plan.bucket_bounds), "hip_graph": not a.no_graph,
+                                     "loss": round(float(c["loss"].detach()), 5)},
+                          "algorithmic_tflops": round(gflop / (dt / a.steps) / 1e3, 2),
+                          "phase_ms": {"train_forward": round(t_fwd, 3), "backward_incl_all_reduce": round(t_bwd, 3),
+                                       "clip_adam": round(t_opt, 3)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

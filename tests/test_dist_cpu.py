@@ -77,7 +77,9 @@ def _grad_worker(rank, world, port, q):
     import random
     rng = random.Random(1234 + 77 * rank)                      # ranks would draw different values on their own
     picks = [sharding.broadcast_choice(1000, rng) for _ in range(5)]
-    q.put((rank, nbytes, ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad, ps[3].grad.clone(), qs[0].grad.clone(), picks))
+    # plain lists, not tensors: torch ships tensors through a queue as shared-memory FILES, which are gone if this
+    # process exits before the parent has opened them (seen once as FileNotFoundError under load)
+    q.put((rank, nbytes, ps[0].grad.tolist(), ps[1].grad.tolist(), ps[2].grad, ps[3].grad.tolist(), qs[0].grad.tolist(), picks))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,11 +100,11 @@ def test_gradient_all_reduce_two_ranks():
         assert p.exitcode == 0
     for rank, nbytes, g0, g1, g2, g3, h0, picks in res:
         assert nbytes == (12 + 5 + 2 + 4 + 4) * 4             # every parameter + one presence word each
-        assert torch.equal(g0, torch.full((3, 4), 1.5))
-        assert torch.equal(g1, torch.arange(5, dtype=torch.float32) * 1.5)
+        assert torch.equal(torch.tensor(g0), torch.full((3, 4), 1.5))
+        assert torch.equal(torch.tensor(g1), torch.arange(5, dtype=torch.float32) * 1.5)
         assert g2 is None                                       # untouched everywhere: the optimiser skips it
-        assert torch.equal(g3, torch.full((4,), 4.0))           # (0 + 8) / 2 on BOTH ranks, on the right parameter
-        assert torch.equal(h0, torch.full((6,), 1.0))
+        assert torch.equal(torch.tensor(g3), torch.full((4,), 4.0))           # (0 + 8) / 2 on BOTH ranks, on the right parameter
+        assert torch.equal(torch.tensor(h0), torch.full((6,), 1.0))
     assert res[0][7] == res[1][7]                               # the sampled indices agree (rank 0 draws)
     import random
     r0 = random.Random(1234)
@@ -148,3 +150,85 @@ def test_bench_entry_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 64
     assert rec["ms_per_step"] >= 2.0                              # rank 1 sleeps 2 ms per step: the slowest rank sets the time
     assert abs(rec["value"] - 2 * 32 * 65536 * 4 / 1e6 / (rec["ms_per_step"] * 4e-3)) / rec["value"] < 1e-3
+
+
+def test_bucket_partition_layout():
+    """The first-stage gradient buffer is cut into buckets in the order the backward finishes the parameters: disjoint
+    cover, every bucket but the last at least the target size, ready steps monotone and closing with the plan."""
+    import random
+    rng = random.Random(3)
+    numels = [rng.choice([3, 32, 192, 36864, 331776, 1128960]) for _ in range(400)]
+    offs, tot = [], 0
+    for n in numels:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    done = sorted(rng.randint(1, 5000) for _ in numels)          # finished in layout order ...
+    done[37], done[38] = done[38], done[37]                       # ... except one pair (lockstep groups finish together)
+    bounds, ready = sharding.bucket_partition(offs, numels, done, tot, 5001, 4 << 20)
+    assert bounds[0][0] == 0 and bounds[-1][1] == tot and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert all((hi - lo) * 4 >= (4 << 20) for lo, hi in bounds[:-1])
+    assert ready == sorted(ready) and ready[-1] == 5001
+    for (lo, hi), r in zip(bounds, ready):                        # a bucket is never sent before its last parameter is final
+        assert all(d <= r for o, d in zip(offs, done) if lo <= o < hi)
+    assert len(bounds) > 10
+
+
+def _bucket_worker(rank, world, port, path):
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (40, 8, 100, 12, 60, 4)]
+    offs, tot = [], 0
+    for p in ps:
+        offs.append(tot)
+        tot += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(tot)
+    views = [flat[o:o + p.numel()] for o, p in zip(offs, ps)]
+    bounds, ready = sharding.bucket_partition(offs, [p.numel() for p in ps], [1, 2, 3, 4, 5, 6], tot, 6, 200)
+    red = sharding.BucketReducer()
+    # the "backward": parameter k's gradient is written at step k + 1; buckets go out as they become final
+    g_local = [torch.randn(p.numel(), generator=torch.Generator().manual_seed(100 * rank + k)) * (3.0 + rank) for k, p in enumerate(ps)]
+    nb = 0
+    for step in range(1, 7):
+        views[step - 1].copy_(g_local[step - 1])
+        while nb < len(ready) and ready[nb] <= step:
+            lo, hi = bounds[nb]
+            red(nb, flat[lo:hi])
+            nb += 1
+    red.finish()
+    for p, v in zip(ps, views):
+        p.grad = v.clone()
+    norm = float(torch.nn.utils.clip_grad_norm_(ps, 1.0))          # AFTER the exchange: the same scale on every rank
+    with open(path, "w") as f:
+        json.dump({"rank": rank, "log": red.log, "bounds": bounds, "ready": ready, "norm": norm,
+                   "grads": [p.grad.tolist() for p in ps], "local": [g.tolist() for g in g_local]}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_two_ranks(tmp_path):
+    """first_train's exchange (BASELINE configs[3]): buckets leave in layout order while the "backward" still runs, every
+    rank ends with the MEAN gradient, and clip_grad_norm_ after the last bucket applies one global scale everywhere
+    (training/step.py:98 on the averaged gradients = the single-process step on the global batch)."""
+    import json
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    paths = [str(tmp_path / f"r{r}.json") for r in range(2)]
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, paths[r])) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0, r1 = (json.load(open(p)) for p in paths)
+    assert r0["bounds"] == r1["bounds"] and r0["ready"] == r1["ready"] and len(r0["bounds"]) >= 2
+    assert [i for i, _ in r0["log"]] == list(range(len(r0["bounds"]))) == [i for i, _ in r1["log"]]      # issue order
+    assert [n for _, n in r0["log"]] == [hi - lo for lo, hi in r0["bounds"]]
+    mean = [(torch.tensor(a) + torch.tensor(b)) / 2 for a, b in zip(r0["local"], r1["local"])]
+    total = torch.sqrt(sum((m.double() ** 2).sum() for m in mean))
+    scale = min(1.0, 1.0 / (float(total) + 1e-6))
+    assert abs(r0["norm"] - float(total)) < 1e-4 and r0["norm"] == r1["norm"] and r0["norm"] > 1.0
+    for g0, g1, m in zip(r0["grads"], r1["grads"], mean):
+        assert g0 == g1                                              # bit-identical on both ranks
+        assert torch.allclose(torch.tensor(g0), m * scale, rtol=1e-5, atol=1e-7)
