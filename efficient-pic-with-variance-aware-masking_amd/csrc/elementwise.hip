@@ -498,19 +498,14 @@ int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, f
 }
 
 int vam_memset_zero(void* ptr, size_t bytes, void* stream) {
+  // Always a KERNEL, never hipMemsetAsync: every node of a captured plan is then a kernel node, ordered like every other
+  // launch of the plan (round 2 saw single elements of a 392-float table left un-cleared behind a memset NODE under
+  // graph replay; scratch/probe/memset_graph.hip is the stand-alone probe of that pattern).
   VAM_REQUIRE(ptr && bytes > 0, "vam_memset_zero: bad arguments");
-  // A kernel, not hipMemsetAsync: inside a captured hipGraph the memset NODE in front of a kernel that accumulates into
-  // the cleared buffer with atomics (the relative-position-bias gradient, csrc/train_gs.hip) intermittently left
-  // elements uncleared / garbage (values of 1e14 ... 1e33 in a 392-float table, seen only under graph replay: one
-  // poisoned element sends clip_grad_norm_ to zero and the refine_gs --lrp loop diverged).  As a kernel node it is
-  // ordered like every other launch of the plan.
-  if ((((uintptr_t)ptr) & 3) == 0 && (bytes & 3) == 0) {
-    const long n = (long)(bytes >> 2);
-    hipLaunchKernelGGL(zero_words_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned*)ptr, n);
-    return check_launch("zero_words_kernel");
-  }
-  VAM_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream));
-  return VAM_OK;
+  VAM_REQUIRE((((uintptr_t)ptr) & 3) == 0 && (bytes & 3) == 0, "vam_memset_zero: pointer and size must be multiples of 4 bytes");
+  const long n = (long)(bytes >> 2);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned*)ptr, n);
+  return check_launch("zero_words_kernel");
 }
 
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream) {

@@ -133,12 +133,11 @@ int vam_graph_launch(void* exec, void* stream) {
 }
 
 int vam_graph_destroy(void* exec) {
-  if (exec) {
-    // a plan that is dropped (weights edited, storage mode switched) may still have replays in flight: the executable
-    // graph must outlive them (destroying it under a running launch crashed a later hipGraphLaunch, intermittently)
-    (void)hipDeviceSynchronize();
-    VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
-  }
+  // The CALLER guarantees that no launch of this executable graph is in flight and that the calling thread is not
+  // capturing (ops.Graph parks dropped handles and destroys them from the next plan entry point, after synchronising the
+  // stream they were last launched on).  Nothing is synchronised here: a device-wide wait from a destructor is illegal
+  // inside another plan's stream capture and hid the ordering the caller has to provide anyway.
+  if (exec) VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
   return VAM_OK;
 }
 

@@ -514,6 +514,12 @@ class FullTrainPlan:
             self.stream = torch.cuda.Stream(device=self.device)
         return self.stream
 
+    def close(self):
+        for g in list(self.fwd_graphs.values()) + [g for gs in self.bwd_graphs.values() for g in gs]:
+            g.close()
+        self.fwd_graphs.clear()
+        self.bwd_graphs.clear()
+
     def set_noise(self, noise=None):
         for key, v in (("y", self.noise_y), ("z", self.noise_z)):
             if noise is not None and key in noise:
@@ -527,9 +533,9 @@ class FullTrainPlan:
         self.generation += 1
         sig = tuple(p.data_ptr() for p in self.params)
         if getattr(self, "_ptr_sig", sig) != sig:          # parameter storage replaced: captured pointers are stale
-            self.fwd_graphs.clear()
-            self.bwd_graphs.clear()
+            self.close()
         self._ptr_sig = sig
+        ops.drain_graveyard()
         cur = torch.cuda.current_stream(self.device)
         st = self._own_stream()
         st.wait_stream(cur)

@@ -189,8 +189,7 @@ class VarianceMaskingPIC(CompressionModel):
             scale_table = get_scale_table()
         self.gaussian_conditional.update_scale_table([float(s) for s in scale_table])
         self.entropy_bottleneck.update(force=force)
-        self._plans.clear()
-        self._dec_plans.clear()
+        self._drop_plans()
         return True
 
     def load_state_dict(self, state_dict, strict=True):
@@ -198,15 +197,24 @@ class VarianceMaskingPIC(CompressionModel):
                             ["_quantized_cdf", "_offset", "_cdf_length", "scale_table"], state_dict)
         _resize_cdf_buffers(self.entropy_bottleneck, "entropy_bottleneck",
                             ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
-        self._plans.clear()
-        self._dec_plans.clear()
+        self._drop_plans()
         for em in (self.gaussian_conditional, self.entropy_bottleneck):      # loaded CDF tables replace the cached host copies
             object.__setattr__(em, "_tables_generation", getattr(em, "_tables_generation", 0) + 1)
         return nn.Module.load_state_dict(self, state_dict, strict=strict)
 
-    def _apply(self, fn, *a, **k):
+    def _drop_plans(self):
+        """Forget every plan: their executable graphs are handed to ops' deferred-destroy list explicitly (not left to
+        whenever the garbage collector finds the plans' reference cycles) and destroyed at the next plan entry point,
+        after their last replay has finished."""
+        for p in list(self._plans.values()) + list(self._dec_plans.values()):
+            close = getattr(p, "close", None)
+            if close is not None:
+                close()
         self._plans.clear()
         self._dec_plans.clear()
+
+    def _apply(self, fn, *a, **k):
+        self._drop_plans()
         self.__dict__.pop("_sig_params", None)
         return super()._apply(fn, *a, **k)
 
@@ -286,6 +294,9 @@ class VarianceMaskingPIC(CompressionModel):
         if p is not None and p.wsig != wsig:
             p = None                # a parameter was edited in place (param.data.copy_, nn.init, optimizer step)
         if p is None:
+            old = self._plans.pop(key, None)
+            if old is not None:
+                old.close()
             p = _FsqPlan(self, B, H, W, base_only, rem_idx, x.device, symbols=symbols, train=train, own_ck=own_ck,
                          train_gs=train_gs, train_lrp=train_lrp)
             p.wsig = wsig
@@ -1145,6 +1156,15 @@ class _FsqPlan:
                            [dict(act=L.ACT_HALF_TANH, post=sl(rq, j), post2=sl(yb, j))], heads=heads)              # pic.py:635-641
 
     # -------------------------------------------------------------------------------------------
+    def close(self):
+        """Give up the executable graphs of this plan (ops.Graph.close: destroyed at the next safe point)."""
+        for g in list(self.graphs.values()) + [getattr(self, "_bwd_graph", None), getattr(self, "_gs_bwd_graph", None),
+                                               getattr(self.plan, "_graph", None)]:
+            if g is not None:
+                g.close()
+        self.graphs.clear()
+        self._bwd_graph = self._gs_bwd_graph = None
+
     def set_noise(self, noise=None):
         """Training: U(-.5,.5) for the likelihood proxies; ``noise`` = {"y": NCHW, "z": NCHW} injects fixed draws
         (parity tests), otherwise torch's generator fills the buffers like the reference's ``uniform_``."""
@@ -1187,15 +1207,14 @@ class _FsqPlan:
         if self.train_gs:
             sig = tuple(p.data_ptr() for p in self.gs_params)
             if getattr(self, "_gs_ptr_sig", sig) != sig:       # parameter storage replaced: captured pointers are stale
-                self.graphs.clear()
-                self._gs_bwd_graph = None
+                self.close()
             self._gs_ptr_sig = sig
         if self.train and self.rem_idx is not None:
             sig = tuple(p.data_ptr() for p in self.rem_params)
             if getattr(self, "_ptr_sig", sig) != sig:          # parameter storage replaced: captured pointers are stale
-                self.graphs.clear()
-                self._bwd_graph = None
+                self.close()
             self._ptr_sig = sig
+        ops.drain_graveyard()                          # dropped plans' graphs: destroyed here, outside any capture
         cur = torch.cuda.current_stream(self.x_in.device)
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.x_in.device)
@@ -1215,6 +1234,8 @@ class _FsqPlan:
                     g = ops.Graph()
                     g.capture(self.plan.run)
                     if len(self.graphs) > 32:
+                        for g_ in self.graphs.values():
+                            g_.close()
                         self.graphs.clear()
                     self.graphs[(self.pr, self.ck_pr)] = g
                 g.launch()

@@ -576,31 +576,74 @@ def sqdiff_sum(a: torch.Tensor, b: torch.Tensor, acc: torch.Tensor):
 
 
 # --------------------------------------------------------------------------- graphs / profiling
+_CAPTURING = 0                      # depth of stream captures in progress on this (single) host thread
+_GRAVEYARD: list = []               # (exec handle, torch stream it was last launched on) of dropped graphs
+
+
 class Graph:
-    """hipGraph capture of a sequence of libvampic launches on the current stream."""
+    """hipGraph capture of a sequence of libvampic launches on the current stream.
+
+    Lifetime: an executable graph must outlive its last replay, and it must not be destroyed while the host thread is
+    capturing (the round-2 crash: ``net.update()`` dropped plans whose graphs had replays in flight on their private
+    streams; their destructors ran whenever the cyclic garbage collector got to them — possibly inside the next plan's
+    capture — and the following ``hipGraphLaunch`` faulted).  So nothing is destroyed from ``__del__``: a dropped graph
+    (``close()`` or garbage collection) only parks its handle, and :func:`drain_graveyard` — called by the plans at
+    their entry points, never during a capture — synchronises the stream each handle was last launched on and then
+    destroys it, checking the return code."""
 
     def __init__(self):
         self.exec = C.c_void_p(None)
+        self.last_stream = None
 
     def capture(self, fn):
+        global _CAPTURING
+        drain_graveyard()
         lib = L.load()
         s = stream_ptr()
         L.check(lib.vam_graph_begin(s), "vam_graph_begin")
+        _CAPTURING += 1
         try:
             fn()
         finally:
+            _CAPTURING -= 1
             rc = lib.vam_graph_end(s, C.byref(self.exec))
         L.check(rc, "vam_graph_end")
 
     def launch(self):
-        L.check(L.load().vam_graph_launch(self.exec, stream_ptr()), "vam_graph_launch")
+        self.last_stream = torch.cuda.current_stream()
+        L.check(L.load().vam_graph_launch(self.exec, self.last_stream.cuda_stream), "vam_graph_launch")
+
+    def close(self):
+        """Give the executable graph up; it is destroyed at the next safe point."""
+        if self.exec:
+            _GRAVEYARD.append((self.exec.value, self.last_stream))
+            self.exec = C.c_void_p(None)
 
     def __del__(self):
         try:
-            if self.exec:
-                L.load().vam_graph_destroy(self.exec)
+            self.close()                # no HIP call here: see the class docstring
         except Exception:
             pass
+
+
+def drain_graveyard():
+    """Destroy the executable graphs dropped since the last call.  No-op while a capture is in progress."""
+    if _CAPTURING or not _GRAVEYARD:
+        return
+    dead = list(_GRAVEYARD)
+    del _GRAVEYARD[:]
+    seen = set()
+    for _, st in dead:
+        if st is not None and st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            st.synchronize()            # the last replay of every dropped graph has finished
+    lib = L.load()
+    for handle, _ in dead:
+        L.check(lib.vam_graph_destroy(C.c_void_p(handle)), "vam_graph_destroy")
+
+
+def graveyard_size() -> int:
+    return len(_GRAVEYARD)
 
 
 _PROF_ON = False

@@ -240,7 +240,8 @@ int vam_dequantize(const int32_t* sym, int ld_sym, const float* mu, int ld_mu, f
 /* out[p, c] = a[p, c] + b[p, c]   (channel windows) — mu_total = mu + yhat_base (pic.py:603) */
 int vam_add(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out,
             long n_pix, int C, void* stream);
-/* hipMemsetAsync(ptr, 0, bytes) on the stream (accumulators are cleared inside the captured graph) */
+/* Zero-fill KERNEL on the stream (ptr and bytes multiples of 4): accumulators are cleared inside the captured graph, where
+ * every node is a kernel node */
 int vam_memset_zero(void* ptr, size_t bytes, void* stream);
 /* sum((a-b)^2) accumulated in double into acc[0] (PSNR, utility/functions.py:172-174) */
 int vam_sqdiff_sum(const float* a, const float* b, long n, double* acc, void* stream);
@@ -361,6 +362,7 @@ int vam_rans_decode(const uint8_t* in_host, long n_bytes, const int32_t* indexes
 int vam_graph_begin(void* stream);
 int vam_graph_end(void* stream, void** graph_exec_out);
 int vam_graph_launch(void* graph_exec, void* stream);
+/* The caller guarantees that no launch of graph_exec is in flight and that the calling thread is not capturing. */
 int vam_graph_destroy(void* graph_exec);
 
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).

@@ -1,0 +1,41 @@
+"""Plan / hipGraph lifetime (round-2 host segfault): dropping plans between replays."""
+import copy
+import gc
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vampic.synth as synth     # noqa: E402
+from vampic import ops           # noqa: E402
+
+
+def test_dropping_plans_between_graph_replays(gpu_model):
+    """The sequence of the crash record (gpurun_out/full_gpu_r02d.log: `codec` fixture -> net.update() -> _plans.clear()
+    with replays of the dropped plans' graphs possibly still running, then capture + launch of a new plan): dropped
+    executable graphs are only PARKED (no HIP call from a destructor / during a capture) and destroyed at the next plan
+    entry point after their stream has been synchronised.  Runs once — no loops."""
+    net = copy.deepcopy(gpu_model[0])
+    x = synth.synth_image(2, 64, 128, seed=5).cuda()
+    with torch.no_grad():
+        a = net.forward_single_quality(x, 2.5)            # capture + replay on the model's private stream
+        a0 = net.forward_single_quality(x, 0)
+        ops.drain_graveyard()
+        assert ops.graveyard_size() == 0
+        net.update()                                      # drops both plans, replays possibly in flight
+        parked = ops.graveyard_size()
+        assert parked >= 2, "update() must hand the plans' graphs to the deferred-destroy list explicitly"
+        gc.collect()                                      # the collector finding the plans' cycles adds nothing and calls no HIP
+        assert ops.graveyard_size() == parked
+        b = net.forward_single_quality(x, 2.5)            # entry point: drain (sync the old stream, destroy), capture, replay
+        assert ops.graveyard_size() == 0
+        assert torch.equal(a["x_hat"], b["x_hat"]) and torch.equal(a["mask"], b["mask"])
+        net.load_state_dict(net.state_dict())             # the other two paths that drop plans
+        c = net.forward_single_quality(x, 0)
+        net.float()
+        d = net.forward_single_quality(x, 2.5)
+        assert torch.equal(a0["x_hat"], c["x_hat"]) and torch.equal(a["x_hat"], d["x_hat"])
+    torch.cuda.synchronize()
+    ops.drain_graveyard()
+    assert ops.graveyard_size() == 0

@@ -194,3 +194,14 @@ def test_finetune_driver_host_logic():
     assert out["x_hat"].grad is not None                       # the distortion is the trained term
     r = FT.RateLoss(device="cpu")(out, x)
     assert torch.allclose(r["loss"], torch.log(out["likelihoods"]["y"]).sum() / den + 2 * torch.log(out["likelihoods"]["z"]).sum() / den)
+
+
+def test_memset_zero_is_a_kernel_with_word_granularity():
+    """vam_memset_zero has no hipMemsetAsync fallback any more (every node of a captured plan is a kernel node): odd
+    pointers / sizes are rejected before anything is launched."""
+    import ctypes as C
+    from vampic import _lib as L
+    lib = L.load()
+    assert lib.vam_memset_zero(C.c_void_p(0x1002), 8, None) == -1
+    assert lib.vam_memset_zero(C.c_void_p(0x1000), 6, None) == -1
+    assert b"multiples of 4" in lib.vam_last_error()
