@@ -118,7 +118,8 @@ _SIGNATURES = {
     "vam_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_gauss_train": (C.c_int, [C.c_void_p, C.c_int] * 10 + [C.c_long, C.c_int, C.c_void_p]),
     "vam_train_elementwise": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
-    "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    "vam_win_attention_bwd_workspace": (C.c_size_t, [C.c_int] * 5),
+    "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
                               + [C.c_int] * 7 + [C.c_void_p]),
     "vam_eb_train_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_void_p]),

@@ -1451,8 +1451,18 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.Cin = cin; p.Kc = (cin + pbk - 1) / pbk; p.Kc16 = (cin + PK - 1) / PK;
     p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
     p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
-    p.Cq = c.Cq; p.act = c.act; p.flags = c.flags;
-    if (conv_mode() == 1 && !c_w16 && !p3_in && c.n_seg == 1 && dual_tap(cin, c.kh * c.kw)) p.flags |= VAM_CONVI_DUAL;
+    constexpr int PUBLIC_FLAGS = VAM_CONV_SQUARE_IN | VAM_CONV_PS2 | VAM_CONV_OUT_NCHW | VAM_CONV_IN_BF3 | VAM_CONV_OUT_BF3 |
+                                 VAM_CONV_W_BF16 | VAM_CONV_IN_BF16 | VAM_CONV_OUT_BF16 | VAM_CONV_AUX_BF16;
+    VAM_REQUIRE((c.flags & ~PUBLIC_FLAGS) == 0, "conv[%d]: unknown flag bits 0x%x", i, c.flags & ~PUBLIC_FLAGS);
+    p.Cq = c.Cq; p.act = c.act; p.flags = c.flags & PUBLIC_FLAGS;      // bits 29 / 30 are the kernel's own
+    // 16-channel multi-tap problems: vam_pack_conv_weights lays the weights out two taps per 32-channel chunk in the
+    // split-operand mode (dual_tap), and ONLY the dual-tap indexing reads that layout — so every such problem must be one
+    // the dual path takes (one fp32 segment); anything else would read dual-packed weights with plain indexing
+    if (conv_mode() == 1 && !c_w16 && dual_tap(cin, c.kh * c.kw)) {
+      VAM_REQUIRE(!p3_in && c.n_seg == 1, "conv[%d]: a 16-channel multi-tap problem takes one fp32 input segment (its weights are "
+                  "packed two taps per chunk)", i);
+      p.flags |= VAM_CONVI_DUAL;
+    }
     {
       // the kernel addresses every input segment with 32-bit byte offsets inside a 2^31-byte window
       const double in_pix = (double)c.B * c.H * c.W;

@@ -142,10 +142,14 @@ __global__ void ew_kernel(const EwArgs a) {
 //   S = (q*scale) k^T + bias + shift mask ; P = softmax(S) ; O = P v
 //   dV_j = sum_i P_ij dO_i ; dP_ij = dO_i . v_j ; dS_ij = P_ij (dP_ij - sum_j' P_ij' dP_ij') ;
 //   dq_i = scale * sum_j dS_ij k_j ; dk_j = sum_i dS_ij (scale q_i) ; dtable[ridx(i,j)][head] += dS_ij
+// The relative-position-bias gradient is DETERMINISTIC: a block (one wave) sums its own contributions in LDS (ds_add of a
+// single wave executes in lane order), writes them to its row of `partial` [blocks of one head group][HPW * NT], and
+// bias_grad_reduce_kernel adds the rows in block order — no global float atomics, so refine_gs / first_train gradients
+// are bit-reproducible run to run and rank to rank.
 template <int WS, int HD>
 __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const float* __restrict__ qkv, int ld_qkv, const float* __restrict__ dout,
                                                           int ld_do, float* __restrict__ dqkv, int ld_dq,
-                                                          const float* __restrict__ table, float* __restrict__ dtable,
+                                                          const float* __restrict__ table, float* __restrict__ partial,
                                                           int B, int H, int W, int C, int heads, int shift, float scale) {
   constexpr int N = WS * WS;
   constexpr int HPW = 64 / N;
@@ -274,10 +278,26 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const float* __restric
     *reinterpret_cast<float4*>(dst + C + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
     *reinterpret_cast<float4*>(dst + 2 * C + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
   }
-  for (int i = lane; i < HPW * NT; i += 64) {
-    const int h2 = i / NT, r = i - h2 * NT;
-    atomicAdd(dtable + r * heads + hg * HPW + h2, sT[i]);
+  float* row = partial + (size_t)blockIdx.x * (HPW * NT);
+  for (int i = lane; i < HPW * NT; i += 64) row[i] = sT[i];
+}
+
+// dtable[r][hg * hpw + h2] = sum over the blocks of head group hg (block id = win * groups + hg), in block order
+__global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dtable, long n_win,
+                                                               int groups, int hpw, int nt, int heads) {
+  __shared__ float red[256];
+  const int o = blockIdx.x;                       // output element: (hg, h2, r)
+  const int hg = o / (hpw * nt), i = o - hg * (hpw * nt);
+  const int h2 = i / nt, r = i - h2 * nt;
+  float s = 0.f;
+  for (long w = threadIdx.x; w < n_win; w += 256) s += partial[((size_t)w * groups + hg) * (hpw * nt) + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {          // fixed tree
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) dtable[r * heads + hg * hpw + h2] = red[0];
 }
 
 static inline unsigned sgrid2(long n, int block) {
@@ -336,10 +356,16 @@ int vam_train_elementwise(int op, const vam_ew* e, void* stream) {
   }
 }
 
+size_t vam_win_attention_bwd_workspace(int B, int H, int W, int heads, int ws) {
+  if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || (ws != 4 && ws != 8)) return 0;
+  const size_t nt = (size_t)(2 * ws - 1) * (2 * ws - 1);
+  return (size_t)B * (H / ws) * (W / ws) * heads * nt * sizeof(float);      // [windows * head groups][hpw * nt]
+}
+
 int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int ld_do, float* dqkv, int ld_dq,
-                          const float* table, float* dtable, int B, int H, int W, int C, int heads, int ws, int shift,
-                          void* stream) {
-  VAM_REQUIRE(qkv && dout && dqkv && table && dtable && B > 0 && H > 0 && W > 0, "vam_win_attention_bwd: bad arguments");
+                          const float* table, float* dtable, float* workspace, int B, int H, int W, int C, int heads, int ws,
+                          int shift, void* stream) {
+  VAM_REQUIRE(qkv && dout && dqkv && table && dtable && workspace && B > 0 && H > 0 && W > 0, "vam_win_attention_bwd: bad arguments");
   VAM_REQUIRE((ws == 4 || ws == 8) && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws, "vam_win_attention_bwd: window");
   VAM_REQUIRE(heads > 0 && C % heads == 0 && ld_qkv >= 3 * C && ld_dq >= 3 * C && ld_do >= C, "vam_win_attention_bwd: channels");
   VAM_REQUIRE(ld_qkv % 4 == 0 && ld_dq % 4 == 0 && ld_do % 4 == 0 && (((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0, "vam_win_attention_bwd: alignment");
@@ -355,8 +381,11 @@ int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int l
     static bool attr = false;                                                                                              \
     if (!attr) { (void)hipFuncSetAttribute((const void*)win_attn_bwd_kernel<WS_, HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; } \
     hipLaunchKernelGGL((win_attn_bwd_kernel<WS_, HD_>), dim3((unsigned)nblk), dim3(64), smem, s, qkv, ld_qkv, dout, ld_do, dqkv, \
-                       ld_dq, table, dtable, B, H, W, C, heads, shift, scale);                                             \
-    return check_launch("win_attn_bwd_kernel");                                                                            \
+                       ld_dq, table, workspace, B, H, W, C, heads, shift, scale);                                          \
+    if (int rc_ = check_launch("win_attn_bwd_kernel")) return rc_;                                                         \
+    hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((unsigned)(heads * nt)), dim3(256), 0, s, workspace, dtable,          \
+                       (long)B * (H / ws) * (W / ws), heads / hpw, hpw, nt, heads);                                        \
+    return check_launch("bias_grad_reduce_kernel");                                                                        \
   }
   VAM_ATT_BWD(8, 24) VAM_ATT_BWD(4, 40) VAM_ATT_BWD(4, 80)
 #undef VAM_ATT_BWD

@@ -312,8 +312,10 @@ def _attention_block_bwd(bw, pk, r: dict, dout: View, grads, need_dx: bool) -> O
     dqkv = bw.buf(x.B, x.H, x.W, 3 * x.C)
     tab = wa.attn.relative_position_bias_table
     dtab = grads[id(tab)]
-    bw.call(lambda: (ops.memset_zero(dtab), ops.win_attention_bwd(r["qkv"], d_att, dqkv, tab, dtab, x.C, wa.num_heads,
-                                                                 wa.window_size, wa.shift_size)), "win_attention bwd")
+    wsp = ops.win_attention_bwd_workspace(r["qkv"], wa.num_heads, wa.window_size)
+    bw.keep.append(wsp)
+    bw.call(lambda: ops.win_attention_bwd(r["qkv"], d_att, dqkv, tab, dtab, x.C, wa.num_heads, wa.window_size, wa.shift_size, wsp),
+            "win_attention bwd")
     dx_b = _conv_bwd(bw, pk, wa.attn.qkv, x, dqkv, grads, need_dx, dx_post=d)          # + the shortcut of the Swin block
     d = da
     for i, rr in enumerate(reversed(r["a_tape"])):

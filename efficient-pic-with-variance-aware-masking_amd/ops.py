@@ -524,12 +524,21 @@ def flat_view(t: torch.Tensor, width: int = 4) -> View:
     return View(t.view(1, 1, t.numel() // width, width), 0, width)
 
 
+def win_attention_bwd_workspace(qkv: View, heads: int, ws: int) -> torch.Tensor:
+    """Caller-owned scratch of vam_win_attention_bwd (per-block partial bias-table gradients)."""
+    n = L.load().vam_win_attention_bwd_workspace(qkv.B, qkv.H, qkv.W, heads, ws)
+    return torch.empty(n // 4, dtype=torch.float32, device=qkv.buf.device)
+
+
 def win_attention_bwd(qkv: View, dout: View, dqkv: View, table: torch.Tensor, dtable: torch.Tensor, C_: int, heads: int,
-                      ws: int, shift: int):
+                      ws: int, shift: int, workspace: Optional[torch.Tensor] = None):
     assert dtable.shape == table.shape and dtable.is_contiguous()
+    if workspace is None:
+        workspace = win_attention_bwd_workspace(qkv, heads, ws)
+    assert workspace.numel() * 4 >= L.load().vam_win_attention_bwd_workspace(qkv.B, qkv.H, qkv.W, heads, ws)
     L.check(L.load().vam_win_attention_bwd(qkv.ptr, qkv.ld, dout.ptr, dout.ld, dqkv.ptr, dqkv.ld, table.data_ptr(),
-                                           dtable.data_ptr(), qkv.B, qkv.H, qkv.W, C_, heads, ws, shift, stream_ptr()),
-            "vam_win_attention_bwd")
+                                           dtable.data_ptr(), workspace.data_ptr(), qkv.B, qkv.H, qkv.W, C_, heads, ws, shift,
+                                           stream_ptr()), "vam_win_attention_bwd")
 
 
 def colsum(dy: View, out: torch.Tensor):

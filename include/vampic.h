@@ -324,10 +324,13 @@ typedef struct vam_ew {
 } vam_ew;
 int vam_train_elementwise(int op, const vam_ew* e, void* stream);
 /* Backward of vam_win_attention: dqkv [B,H,W,3C] (dq | dk | dv, same layout as qkv) from dout = dL/d(attention output),
- * and the relative-position-bias gradient ACCUMULATED into dtable [(2ws-1)^2][heads] (clear it first). */
+ * and the relative-position-bias gradient WRITTEN to dtable [(2ws-1)^2][heads].  Deterministic: every (window, head group)
+ * block writes its partial table into `workspace` (vam_win_attention_bwd_workspace bytes, caller-owned) and a second
+ * launch adds the rows in a fixed order — no float atomics in global memory. */
+size_t vam_win_attention_bwd_workspace(int B, int H, int W, int heads, int ws);
 int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int ld_do, float* dqkv, int ld_dq,
-                          const float* table, float* dtable, int B, int H, int W, int C, int heads, int ws, int shift,
-                          void* stream);
+                          const float* table, float* dtable, float* workspace, int B, int H, int W, int C, int heads, int ws,
+                          int shift, void* stream);
 
 /* ------------------------------------------------------------------ first-stage training (configs[3]) */
 /* Backward of the training-mode entropy bottleneck (entropy_models.py:403-436,449-492 with quantize "noise"): for
