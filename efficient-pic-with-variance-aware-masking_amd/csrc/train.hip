@@ -17,9 +17,13 @@ namespace vam {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // dW[n][c_off + c][ty][tx] = sum_p dY[p][n] * X[pix(p) + (ty - pad, tx - pad)][c]      (stride 1)
-// grid = (taps * N/32 tiles * C/32 tiles [max over the group], problems).  8 waves split the pixels in batches of
-// 32 (16 MFMAs with all 32 loads of a batch in flight: the loop is latency-bound otherwise); fixed-order LDS
-// reduction.  The block of tap 0 / channel tile 0 / c_off 0 also produces db[n] = sum_p dY[p][n].
+// grid = (taps * N/32 tiles * C/32 tiles * pixel splits [max over the group], problems).  8 waves split the pixels of the
+// block's range in batches of 32 (16 MFMAs with all 32 loads of a batch in flight: the loop is latency-bound otherwise);
+// fixed-order LDS reduction.  The block of tap 0 / channel tile 0 / c_off 0 also produces db[n] = sum_p dY[p][n].
+// Pixel splits (first-stage training: 1x1 layers on 131072 ... 524288 pixels have only (N/32)(C/32) = 18 ... 36 weight
+// tiles, far fewer than the chip's 256 CUs): split s of S handles a contiguous pixel range and writes its partial tile to
+// the caller-owned workspace [S][N][C][taps] (+ [S][N] for the bias); wgrad_reduce_kernel adds the S partials in split
+// order.  Deterministic either way: no float atomics.
 constexpr int WG_WAVES = 8, WG_BATCH = 16;   // MFMAs per batch; each covers 2 pixels
 
 struct WgradArgs {
@@ -32,8 +36,12 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   const vam_wgrad& pr = args.p[blockIdx.y];
   const int kh = pr.kh, kw = pr.kw, taps = kh * kw;
   const int n_tiles = (pr.N + 31) / 32, c_tiles = (pr.C + 31) / 32;
+  const int per = taps * n_tiles * c_tiles;
+  const int S = pr.splits > 1 ? pr.splits : 1;
   int bid = blockIdx.x;
-  if (bid >= taps * n_tiles * c_tiles) return;
+  if (bid >= per * S) return;
+  const int split = bid / per;
+  bid -= split * per;
   const int tap = bid % taps;
   bid /= taps;
   const int n0 = (bid % n_tiles) * 32, c0 = (bid / n_tiles) * 32;
@@ -45,6 +53,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   const int Hx = stride == 2 ? pr.Hx : H, Wx = stride == 2 ? pr.Wx : W;
   const long HWx = (long)Hx * Wx;
   const long P = (long)pr.B * HW;
+  const long chunk = ((P + S - 1) / S + 2 * WG_BATCH - 1) / (2 * WG_BATCH) * (2 * WG_BATCH);
+  const long p_begin = (long)split * chunk;
+  const long p_end = p_begin + chunk < P ? p_begin + chunk : P;
   const float* __restrict__ x = pr.x;
   const float* __restrict__ dy = pr.dy;
   const int ld_x = pr.ld_x, ld_dy = pr.ld_dy;
@@ -54,14 +65,14 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float bsum = 0.f;
-  for (long pb = (long)wid * (2 * WG_BATCH); pb < P; pb += (long)WG_WAVES * 2 * WG_BATCH) {
+  for (long pb = p_begin + (long)wid * (2 * WG_BATCH); pb < p_end; pb += (long)WG_WAVES * 2 * WG_BATCH) {
     float a[WG_BATCH], b[WG_BATCH];
 #pragma unroll
     for (int i = 0; i < WG_BATCH; ++i) {
       const long p = pb + 2 * i + lh;
       a[i] = 0.f;
       b[i] = 0.f;
-      if (p < P) {
+      if (p < p_end) {
         if (n_ok) a[i] = dy[p * ld_dy + n0 + l31];
         const int bi = (int)(p / HW);
         const int r = (int)(p - (long)bi * HW);
@@ -81,39 +92,75 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
   redb[wid][lh][l31] = bsum;
   __syncthreads();
+  float* part = S > 1 ? pr.workspace + (size_t)split * ((size_t)pr.N * pr.C * taps + pr.N) : nullptr;
   for (int i = threadIdx.x; i < 32 * 32; i += WG_WAVES * 64) {
     const int n = i >> 5, c = i & 31;
     if (n0 + n < pr.N && c0 + c < pr.C) {
       float v = red[0][n][c];
 #pragma unroll
       for (int k = 1; k < WG_WAVES; ++k) v += red[k][n][c];
-      pr.dw[(((long)(n0 + n) * pr.cin_total + pr.c_off + c0 + c) * kh + ty) * kw + tx] = v;
+      if (part) part[((size_t)(n0 + n) * pr.C + c0 + c) * taps + tap] = v;
+      else pr.dw[(((long)(n0 + n) * pr.cin_total + pr.c_off + c0 + c) * kh + ty) * kw + tx] = v;
     }
   }
   if (want_db && threadIdx.x < 32 && n0 + threadIdx.x < pr.N) {
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < WG_WAVES; ++k) v += redb[k][0][threadIdx.x] + redb[k][1][threadIdx.x];
-    pr.db[n0 + threadIdx.x] = v;
+    if (part) part[(size_t)pr.N * pr.C * taps + n0 + threadIdx.x] = v;
+    else pr.db[n0 + threadIdx.x] = v;
   }
 }
 
-// db[n] = sum_p dY[p][n]  (one block per 32 channels, fixed order)
+// dw / db = sum over the pixel splits, in split order (problems without splits: nothing to do)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs args) {
+  const vam_wgrad& pr = args.p[blockIdx.y];
+  const int S = pr.splits;
+  if (S <= 1) return;
+  const int taps = pr.kh * pr.kw;
+  const size_t n_w = (size_t)pr.N * pr.C * taps, stride = n_w + pr.N;
+  const bool want_db = pr.db != nullptr && pr.c_off == 0;
+  const size_t total = n_w + (want_db ? pr.N : 0);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v = pr.workspace[i];
+    for (int s = 1; s < S; ++s) v += pr.workspace[(size_t)s * stride + i];
+    if (i < n_w) {
+      const int tap = (int)(i % taps);
+      const size_t nc = i / taps;
+      const int c = (int)(nc % pr.C), n = (int)(nc / pr.C);
+      pr.dw[((size_t)n * pr.cin_total + pr.c_off + c) * taps + tap] = v;
+    } else {
+      pr.db[i - n_w] = v;
+    }
+  }
+}
+
+// db[n] = sum_p dY[p][n]: blockIdx.y-th slice of the pixels into partial[y][n] (fixed order inside), then colsum_reduce
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int ld, long P, int N,
                                                      float* __restrict__ out) {
   __shared__ float red[8][32];
   const int n = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  const long chunk = (P + gridDim.y - 1) / gridDim.y;
+  const long p0 = (long)blockIdx.y * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
   float s = 0.f;
   if (n < N)
-    for (long p = g; p < P; p += 8) s += dy[p * ld + n];
+    for (long p = p0 + g; p < p1; p += 8) s += dy[p * ld + n];
   red[g][threadIdx.x & 31] = s;
   __syncthreads();
   if (g == 0 && n < N) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
-    out[n] = t;
+    out[(size_t)blockIdx.y * N + n] = t;
   }
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int S, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float v = partial[n];
+  for (int s = 1; s < S; ++s) v += partial[(size_t)s * N + n];
+  out[n] = v;
 }
 
 __global__ void leaky_bwd_kernel(const float* __restrict__ act, int ld_a, const float* __restrict__ dy, int ld_dy,
@@ -218,9 +265,28 @@ using namespace vam;
 
 extern "C" {
 
+static int wgrad_splits(const vam_wgrad& p) {
+  // enough blocks to fill the chip (4 blocks of 8 waves per CU x 256 CUs, twice over), at least 2048 pixels per split
+  const long per = (long)p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
+  const long P = (long)p.B * p.H * p.W;
+  long s = (2048 + per - 1) / per;
+  const long cap = P / 2048;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  return s < 2 ? 1 : (int)s;
+}
+
+int vam_conv_wgrad_plan(const vam_wgrad* p, size_t* workspace_bytes) {
+  if (!p || p->B <= 0 || p->H <= 0 || p->W <= 0 || p->C <= 0 || p->N <= 0 || p->kh <= 0) return 1;
+  const int s = wgrad_splits(*p);
+  if (workspace_bytes) *workspace_bytes = s > 1 ? (size_t)s * ((size_t)p->N * p->C * p->kh * p->kw + p->N) * sizeof(float) : 0;
+  return s;
+}
+
 int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   VAM_REQUIRE(probs && n_probs >= 1 && n_probs <= VAM_MAX_WGRAD_GROUP, "vam_conv_wgrad_group: 1..%d problems", VAM_MAX_WGRAD_GROUP);
   int max_blocks = 0;
+  long max_red = 0;
   double flops = 0;
   for (int i = 0; i < n_probs; ++i) {
     const vam_wgrad& p = probs[i];
@@ -229,15 +295,28 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     VAM_REQUIRE(p.stride == 0 || p.stride == 1 || (p.stride == 2 && p.kh >= 3 && p.Hx == 2 * p.H && p.Wx == 2 * p.W),
                 "vam_conv_wgrad_group: problem %d: stride %d (1, or 2 with k3 / k5 and x of extent 2H x 2W)", i, p.stride);
     VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
-    int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
+    VAM_REQUIRE(p.splits >= 0 && p.splits <= 256 && (p.splits <= 1 || p.workspace), "vam_conv_wgrad_group: problem %d: %d pixel splits need a workspace "
+                "(vam_conv_wgrad_plan)", i, p.splits);
+    const int S = p.splits > 1 ? p.splits : 1;
+    int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32) * S;
     max_blocks = nb > max_blocks ? nb : max_blocks;
+    if (S > 1) {
+      const long tot = (long)p.N * p.C * p.kh * p.kw + p.N;
+      max_red = tot > max_red ? tot : max_red;
+    }
     flops += 2.0 * p.B * p.H * p.W * (double)p.C * p.N * p.kh * p.kw;
   }
   WgradArgs wa;
   for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
   ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
   hipLaunchKernelGGL(wgrad_kernel, dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
-  return check_launch("wgrad_kernel");
+  if (int rc = check_launch("wgrad_kernel")) return rc;
+  if (max_red > 0) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(max_red, 256) > 1024 ? 1024 : cdiv(max_red, 256), n_probs), dim3(256), 0,
+                       (hipStream_t)stream, wa);
+    return check_launch("wgrad_reduce_kernel");
+  }
+  return VAM_OK;
 }
 
 int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw, int C,
@@ -247,13 +326,24 @@ int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, 
   p.ld_x = ld_x; p.ld_dy = ld_dy; p.B = B; p.H = H; p.W = W; p.kh = kh; p.kw = kw; p.C = C; p.N = N;
   p.cin_total = cin_total; p.c_off = c_off;
   p.stride = 1; p.Hx = H; p.Wx = W;
+  p.splits = 1; p.workspace = nullptr;
   return vam_conv_wgrad_group(&p, 1, stream);
 }
 
-int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream) {
-  VAM_REQUIRE(dy && out && n_pix > 0 && N > 0 && ld >= N, "vam_colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, (hipStream_t)stream, dy, ld, n_pix, N, out);
-  return check_launch("colsum_kernel");
+static int colsum_splits(long n_pix) {
+  long s = n_pix / 4096;
+  return s < 1 ? 1 : (s > 512 ? 512 : (int)s);
+}
+
+size_t vam_colsum_workspace(long n_pix, int N) { return (size_t)colsum_splits(n_pix) * (N > 0 ? N : 0) * sizeof(float); }
+
+int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, float* workspace, void* stream) {
+  VAM_REQUIRE(dy && out && workspace && n_pix > 0 && N > 0 && ld >= N, "vam_colsum: bad arguments");
+  const int S = colsum_splits(n_pix);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32), S), dim3(256), 0, (hipStream_t)stream, dy, ld, n_pix, N, workspace);
+  if (int rc = check_launch("colsum_kernel")) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, workspace, S, N, out);
+  return check_launch("colsum_reduce_kernel");
 }
 
 int vam_leaky_bwd(const float* act, int ld_a, const float* dy, int ld_dy, float* dx, int ld_dx, long n_pix, int C,

@@ -103,6 +103,7 @@ class Plan:
             arr = (L.VamWgrad * len(chunk))(*chunk)
             n = len(chunk)
             self.keep.append(arr)
+            self.keep += [c._ws for c in chunk if getattr(c, "_ws", None) is not None]     # pixel-split scratch (ops.wgrad_problems)
             fl = sum(2.0 * c.B * c.H * c.W * c.C * c.N * c.kh * c.kw for c in chunk)
             self.flops += fl
             self.meta.append({"kind": "wgrad", "flops": fl, "desc": f"{n}x wgrad [{chunk[0].C}->{chunk[0].N} k{chunk[0].kh}]"})

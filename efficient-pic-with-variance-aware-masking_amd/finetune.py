@@ -292,3 +292,54 @@ def train_one_epoch_first_train(model, criterion, train_dataloader: Iterable[tor
         counter += 1
     n = max(n, 1)
     return counter, tot["loss"] / n, tot["bpp_loss"] / n, tot["mse_loss"] / n, tot["bpp_scalable"] / n
+
+
+# ============================================================================= encoder + decoder refinement (--training_type refine_gs_ga)
+class RateDistortionLoss(ScalableRateDistortionLoss):
+    """training/loss.py:67-124: ScalableRateDistortionLoss's arithmetic with the Lagrangian passed per call.  The reference
+    never sets ``self.lmbda`` (:95-96), so calling it without ``lmbda`` fails there too."""
+
+    def __init__(self, weight=255 ** 2, device="cuda"):
+        nn.Module.__init__(self)
+        self.weight, self.device = weight, device
+
+    def forward(self, output, target, lmbda=None):
+        if lmbda is None:
+            raise AttributeError("RateDistortionLoss has no default lmbda (training/loss.py:95-96): pass lmbda=")
+        return ScalableRateDistortionLoss.forward(self, output, target, lmbda=lmbda)
+
+
+def refine_gs_ga_setup(model):
+    """train.py:219-222: ``freeze_all(); unfreeze_decoder(); unfreeze_encoder()`` — the progressive decoder g_s[1] and
+    the enhancement encoder g_a[1] train (pic.py:171-191)."""
+    model.freeze_all()
+    model.unfreeze_decoder()
+    model.unfreeze_encoder()
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def refine_gs_ga_lambdas(lmbda_list: Sequence[float], n_qualities: int) -> List[float]:
+    """train.py:158-166: one Lagrangian per sampled quality, log-spaced between the two ends of ``--lmbda_list``
+    (``torch.logspace(log10(l0), log10(l1), steps=n + 1)[1:]``)."""
+    start, end = math.log10(lmbda_list[0]), math.log10(lmbda_list[1])
+    return torch.logspace(start, end, steps=n_qualities + 1)[1:].tolist()
+
+
+def refine_gs_ga_step(model, criterion, batch: torch.Tensor, optimizer, quality: float, lmbda: float,
+                      clip_max_norm: float = 1.0, noise=None) -> dict:
+    """One step of the ``refine_gs_ga`` schedule: training forward at the sampled quality, rate-distortion loss at that
+    quality's Lagrangian, backward (full_train.FullTrainPlan: gradients reach g_a[1] through the likelihoods and both
+    straight-through paths), exchange, clip, step.  The REFERENCE's loop cannot run this schedule: with ``lmbda_list`` set,
+    training/step.py:84 calls the criterion and discards its result, and the next line reads ``out_criterion`` — a NameError
+    on the first batch.  This mirrors what that line evidently means to do (keep the result)."""
+    from . import sharding as S
+    optimizer.zero_grad()
+    if S.world_size() > 1 and getattr(model, "grad_reducer", None) is None:
+        model.grad_reducer = S.BucketReducer()
+    out = model.forward_single_quality(batch, quality=quality, training=True, noise=noise)
+    crit = criterion(out, batch, lmbda=lmbda)
+    crit["loss"].backward()
+    if clip_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
+    optimizer.step()
+    return crit

@@ -334,15 +334,18 @@ def _deconv_bwd(bw, pk, r: dict, dy: View, grads, need_dx: bool = True) -> Optio
     gw, gb = grads[id(m.weight)], grads[id(m.bias)]
     if dy.C == co:
         bw.wgrad(ops.wgrad_problems([dy], x, gw, None, stride=2))
-        bw.call(lambda: ops.colsum(dy, gb), "deconv bias grad")
+        wsp = ops.colsum_workspace(dy)
+        bw.keep.append(wsp)
+        bw.call(lambda: ops.colsum(dy, gb, wsp), "deconv bias grad")
     else:                                            # zero-padded 3-channel output gradient
         tw = torch.zeros((ci, dy.C, 5, 5), dtype=torch.float32, device=gw.device)
         tb = torch.zeros((dy.C,), dtype=torch.float32, device=gw.device)
-        bw.keep += [tw, tb]
+        wsp = ops.colsum_workspace(dy)
+        bw.keep += [tw, tb, wsp]
         bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2))
         # (torch.mul(.., 1.0, out=..) instead of a contiguous copy_: an element-wise KERNEL node under graph capture, not a
         # device-to-device memcpy node — see vam_memset_zero for what a non-kernel node did in these graphs)
-        bw.call(lambda: (ops.colsum(dy, tb), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
+        bw.call(lambda: (ops.colsum(dy, tb, wsp), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
     if not need_dx:
         return None
     dx = bw.buf(x.B, x.H, x.W, ci)

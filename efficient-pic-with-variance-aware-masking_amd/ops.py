@@ -469,6 +469,11 @@ def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optio
         p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, dy.B, dy.H, dy.W, kh, kw, v.C, n
         p.cin_total, p.c_off = cin_total, off
         p.stride, p.Hx, p.Wx = stride, v.H, v.W
+        nbytes = C.c_size_t(0)
+        p.splits = L.load().vam_conv_wgrad_plan(C.byref(p), C.byref(nbytes))
+        if p.splits > 1:                  # caller-owned scratch for the pixel-split partial tiles; lives with the problem
+            p._ws = torch.empty(nbytes.value // 4, dtype=torch.float32, device=dy.buf.device)
+            p.workspace = p._ws.data_ptr()
         out.append(p)
         off += v.C
     return out
@@ -541,8 +546,14 @@ def win_attention_bwd(qkv: View, dout: View, dqkv: View, table: torch.Tensor, dt
                                            stream_ptr()), "vam_win_attention_bwd")
 
 
-def colsum(dy: View, out: torch.Tensor):
-    L.check(L.load().vam_colsum(dy.ptr, dy.ld, dy.n_pix, dy.C, out.data_ptr(), stream_ptr()), "vam_colsum")
+def colsum_workspace(dy: View) -> torch.Tensor:
+    return torch.empty(L.load().vam_colsum_workspace(dy.n_pix, dy.C) // 4, dtype=torch.float32, device=dy.buf.device)
+
+
+def colsum(dy: View, out: torch.Tensor, workspace: Optional[torch.Tensor] = None):
+    if workspace is None:
+        workspace = colsum_workspace(dy)
+    L.check(L.load().vam_colsum(dy.ptr, dy.ld, dy.n_pix, dy.C, out.data_ptr(), workspace.data_ptr(), stream_ptr()), "vam_colsum")
 
 
 def repack_weights(src: torch.Tensor, dst: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int):

@@ -276,12 +276,19 @@ typedef struct vam_wgrad {
   int stride;         /* 0 or 1: stride 1, pad k/2, x has the extent of dy.  2: a stride-2, pad k/2 convolution (k5: g_a,  */
   int Hx, Wx;         /* k3: h_a) — x is [B, Hx, Wx] (Hx = 2H, Wx = 2W): input pixel = 2*o - k/2 + tap.  Also the   */
                       /* transposed convolutions of g_s: their weight gradient is this with x and dy exchanged      */
+  int splits;         /* 0 / 1: one block per weight tile walks all pixels.  > 1 (from vam_conv_wgrad_plan): the      */
+  float* workspace;   /* pixels are cut into `splits` ranges whose partial tiles go to this caller-owned buffer and   */
+                      /* are added in range order by a second launch (layers with few weight tiles and many pixels)  */
 } vam_wgrad;
+/* Suggested number of pixel splits for a problem (>= 1) and the workspace it needs (0 bytes when 1). */
+int vam_conv_wgrad_plan(const vam_wgrad* problem, size_t* workspace_bytes);
 int vam_conv_wgrad_group(const vam_wgrad* problems, int n_problems, void* stream);
 int vam_conv_wgrad(const float* x, int ld_x, const float* dy, int ld_dy, int B, int H, int W, int kh, int kw,
                    int C, int N, float* dw_oihw, float* db, int cin_total, int c_off, void* stream);
-/* out[n] = sum_p dy[p][n]  (bias gradient) */
-int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, void* stream);
+/* out[n] = sum_p dy[p][n]  (bias gradient): pixel ranges in parallel into `workspace` (vam_colsum_workspace bytes,
+ * caller-owned), then added in range order — deterministic. */
+size_t vam_colsum_workspace(long n_pix, int N);
+int vam_colsum(const float* dy, int ld, long n_pix, int N, float* out, float* workspace, void* stream);
 /* dx = dy * (act > 0 ? 1 : 0.01): LeakyReLU(0.01) backward from its OUTPUT (same sign as its input) */
 int vam_leaky_bwd(const float* act, int ld_a, const float* dy, int ld_dy, float* dx, int ld_dx, long n_pix, int C, void* stream);
 int vam_mul(const float* a, int ld_a, const float* b, int ld_b, float* out, int ld_out, long n_pix, int C, void* stream);

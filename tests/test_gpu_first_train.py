@@ -272,6 +272,38 @@ def test_single_quality_training_step_matches_reference():
     assert torch.equal(force["mask"], torch.cat([O.variance_mask(s_, 2.5) for s_ in sig.chunk(10, 1)], 1))
 
 
+def test_refine_gs_ga_step():
+    """`--training_type refine_gs_ga` (train.py:158-166,219-222): g_s[1] and g_a[1] train, rate-distortion loss at the
+    sampled quality's Lagrangian.  Gradients of the trainable set against the oracle's step at equal decisions; every other
+    parameter keeps grad None and its value through an optimiser step."""
+    from vampic import finetune as ft
+    from test_oracle_golden import train_fixture_inputs
+    net, sd = _model()
+    params = ft.refine_gs_ga_setup(net)
+    assert {n.split(".")[0] + "." + n.split(".")[1] for n, p in net.named_parameters() if p.requires_grad} == {"g_s.1", "g_a.1"}
+    lms = ft.refine_gs_ga_lambdas([0.0055, 0.04], 254)
+    assert len(lms) == 254 and abs(lms[-1] - 0.04) < 1e-6 and lms[0] > 0.0055
+    x, ny, nz = train_fixture_inputs()
+    crit_fn = ft.RateDistortionLoss(device="cuda")
+    with pytest.raises(AttributeError):
+        crit_fn({"x_hat": x.cuda(), "likelihoods": {"y": x.cuda(), "z": x.cuda()}}, x.cuda())
+    out = net.forward_single_quality(x.cuda(), 2.5, training=True, noise={"y": ny, "z": nz})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        crit = crit_fn(out, x.cuda(), lmbda=0.01)
+    crit["loss"].backward()
+    ref, _ = _forced_oracle_step(sd, net, x, ny, nz, [2.5], 0.01, True)
+    want = {k: g for k, g in ref["grads"].items() if k.startswith(("g_s.1.", "g_a.1."))}
+    joint, fam, worst = _compare_grads(net, want)
+    print("refine_gs_ga joint gradient error", joint, worst)
+    assert joint <= 2e-4
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    opt = torch.optim.Adam(params, lr=1e-4)
+    ft.refine_gs_ga_step(net, crit_fn, x.cuda(), opt, 2.5, 0.01, noise={"y": ny, "z": nz})
+    for n, p in net.named_parameters():
+        assert torch.equal(p, before[n]) != n.startswith(("g_s.1.", "g_a.1.")), n
+
+
 def test_adam_loop_lowers_the_loss():
     """Ten Adam steps of the first_train schedule (training/step.py:56-99: zero_grad, forward([0, 10]), criterion, backward,
     clip 1.0, step) on a fixed batch lower the loss; hipGraph replay across the optimiser's in-place updates."""

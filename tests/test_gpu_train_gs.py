@@ -228,9 +228,15 @@ def test_refine_gs_teacher_forced_and_loop(pic_model):
     for n, p in m.named_parameters():
         if not n.startswith("g_s.1."):
             assert torch.equal(p, frozen[n]), n
-    m.unfreeze_encoder()                                          # anything outside the decoder still fails loudly
-    with pytest.raises(NotImplementedError):
-        m.forward_single_quality(x, quality=1.5, training=True)
+    # refine_gs_ga (train.py:219-222: unfreeze_decoder + unfreeze_encoder): beyond the decoder-only plan -> the complete
+    # training plan (full_train.py; parity in tests/test_gpu_first_train.py) — gradients for exactly the trainable set
+    m.unfreeze_encoder()
+    m.zero_grad(set_to_none=True)
+    o = m.forward_single_quality(x, quality=1.5, training=True)
+    (o["x_hat"].mean() + torch.log(o["likelihoods"]["y"]).mean()).backward()
+    for n, p in m.named_parameters():
+        assert (p.grad is not None) == n.startswith(("g_s.1.", "g_a.1.")), n
+        assert p.grad is None or torch.isfinite(p.grad).all()
 
 
 def _train_plan(m, B, H, W):
@@ -329,8 +335,11 @@ def test_refine_gs_lrp_teacher_forced_and_loop(pic_model):
     # an LRP subset, or the LRP stacks at quality 0 (base decoder), is not a schedule of the reference: loud
     for p in m.lrp_transforms_prog[3].parameters():
         p.requires_grad = False
-    with pytest.raises(NotImplementedError):
-        m.forward_single_quality(x, quality=1.5, training=True)
+    m.zero_grad(set_to_none=True)                                  # not a schedule of the reference: the complete training plan serves it
+    o = m.forward_single_quality(x, quality=1.5, training=True)
+    o["x_hat"].mean().backward()
+    assert all(p.grad is None for p in m.lrp_transforms_prog[3].parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.lrp_transforms_prog[2].parameters())
 
 
 def test_refine_gs_epoch_driver(pic_model):
