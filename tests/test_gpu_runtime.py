@@ -21,13 +21,14 @@ def test_dropping_plans_between_graph_replays(gpu_model):
     with torch.no_grad():
         a = net.forward_single_quality(x, 2.5)            # capture + replay on the model's private stream
         a0 = net.forward_single_quality(x, 0)
+        gc.collect()                                      # plans of earlier tests' models: parked by their destructors
         ops.drain_graveyard()
         assert ops.graveyard_size() == 0
         net.update()                                      # drops both plans, replays possibly in flight
         parked = ops.graveyard_size()
         assert parked >= 2, "update() must hand the plans' graphs to the deferred-destroy list explicitly"
-        gc.collect()                                      # the collector finding the plans' cycles adds nothing and calls no HIP
-        assert ops.graveyard_size() == parked
+        gc.collect()                                      # the collector finding the dropped plans' cycles calls no HIP and
+        assert ops.graveyard_size() == parked             # finds nothing left to park
         b = net.forward_single_quality(x, 2.5)            # entry point: drain (sync the old stream, destroy), capture, replay
         assert ops.graveyard_size() == 0
         assert torch.equal(a["x_hat"], b["x_hat"]) and torch.equal(a["mask"], b["mask"])
