@@ -245,7 +245,8 @@ def _out_extent(m, v: View):
 
 # Plane tensors pay off where the consumer's tiles are small (latent-resolution stacks: the split is a sizeable share
 # of their per-chunk work); on the big feature maps the 8-byte plane stores and 1.5x bytes cost more than they save.
-P3_MAX_PIXELS = 16384
+import os as _os
+P3_MAX_PIXELS = int(_os.environ.get("VAMPIC_P3_MAX_PIXELS", "16384"))       # (environment override: A/B measurements)
 
 
 def lower_stack_heads(plan: Plan, stacks: Sequence[nn.Sequential], hyper_inputs: Sequence[View],

@@ -994,7 +994,7 @@ class _FsqPlan:
                 E.lower_stacks(plan, [m.lrp_transforms_prog[j] for j in range(ns)],
                                [msups[j] + [sl(rq_ck, j)] for j in range(ns)], [sl(self.ck, j) for j in range(ns)],
                                [dict(act=L.ACT_HALF_TANH, post=sl(rq_ck, j), post2=sl(yb, j)) for j in range(ns)], heads=heads)
-            att = plan.buf(B, h, w, d)
+            att = self.att = plan.buf(B, h, w, d)
             plan.call(lambda: ops.variance_mask(self.std_p, self.pr, att, n_slice=ns))
             std_f = plan.buf(B, h, w, d)
             mu_f = plan.buf(B, h, w, d) if mu_std else self.mu_p      # without mu_std only sigma is refined (rem_pic.py:214-218)
@@ -1132,7 +1132,7 @@ class _FsqPlan:
         mu_f, std_f = self.mu_p, self.std_p
         if rem_idx is not None:
             self.ck = plan.buf(B, h, w, d)
-            att = plan.buf(B, h, w, d)
+            att = self.att = plan.buf(B, h, w, d)
             std_f = plan.buf(B, h, w, d)
             mu_f = plan.buf(B, h, w, d) if mu_std else self.mu_p
             self.rem_sig = _version_sig(m.post_latent[rem_idx])

@@ -497,7 +497,7 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
                     "std_base": torch.cat(std_b, 1), "z_hat": z_hat, "y": y}
 
         ck = checkpoint_ref.chunk(10, 1) if checkpoint_ref is not None else None
-        mu_tot, std_tot, mu_p, std_p, masks, yhat_p = [], [], [], [], [], []
+        mu_tot, std_tot, mu_p, std_p, masks, yhat_p, atts = [], [], [], [], [], [], []
         n_prog = y.shape[1] // chunk - ns0
         for j in range(n_prog):
             r = ys[ns0 + j] - ys[j] if delta_encode else ys[ns0 + j]      # pic.py:583-584
@@ -513,6 +513,7 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
             std_tot.append(sc)
             if rem and ck is not None and quality > check_levels[0]:
                 att = variance_mask(sc, quality)                      # rem_pic.py:185-192
+                atts.append(att)
                 if mu_std:
                     att = torch.cat([att, att], 1)
                 ri = rem_index(check_levels, quality)
@@ -534,11 +535,14 @@ def forward_single_quality(sd: SD, x: Tensor, quality: float, *, div: int = 320,
             yhat_p.append(rh + yhat_b[j])
         y_prog = torch.cat(yhat_p, 1)
         x_hat = g_s(sd, "g_s.1." if multiple_decoder else "g_s.", y_prog).clamp(0, 1)
-        return {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
-                "y_hat": y_prog, "y_base": y_base, "y_prog": y_prog,
-                "mu_base": torch.cat(mu_b, 1), "mu": torch.cat(mu_p, 1),
-                "std_base": torch.cat(std_b, 1), "std": torch.cat(std_p, 1),
-                "mask": torch.cat(masks, 1), "z_hat": z_hat, "y": y}
+        res = {"x_hat": x_hat, "likelihoods": {"y": torch.cat(lik, 1), "z": z_lik},
+               "y_hat": y_prog, "y_base": y_base, "y_prog": y_prog,
+               "mu_base": torch.cat(mu_b, 1), "mu": torch.cat(mu_p, 1),
+               "std_base": torch.cat(std_b, 1), "std": torch.cat(std_p, 1),
+               "mask": torch.cat(masks, 1), "z_hat": z_hat, "y": y}
+        if atts:          # REM: the attention mask (a threshold decision on the UN-refined sigma, rem_pic.py:185-192) and that sigma
+            res["att"], res["std_raw"] = torch.cat(atts, 1), torch.cat(std_tot, 1)
+        return res
 
 
 # --------------------------------------------------------------------------

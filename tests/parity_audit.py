@@ -30,9 +30,13 @@ THRESH_TOL = 2e-4        # relative distance of the oracle's sigma from the quan
 
 
 def audit(y_gpu: torch.Tensor, out: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor], q: float, *,
-          div: int = 320, chunk: int = 32, max_support: int = 5, all_scalable: bool = True, delta_encode: bool = True) -> dict:
+          div: int = 320, chunk: int = 32, max_support: int = 5, all_scalable: bool = True, delta_encode: bool = True,
+          att_gpu: torch.Tensor = None) -> dict:
     """``y_gpu``: the HIP path's latent y [B, 2*div, h, w]; ``out``: its output dict (cpu tensors); ``ref``: the oracle's
-    dict (holds "y").  Returns counts plus ``violations`` (list of strings; empty = every difference is explained)."""
+    dict (holds "y").  Returns counts plus ``violations`` (list of strings; empty = every difference is explained).
+    REM variants (``ref`` holds "att" / "std_raw"): the REM's attention mask is a SECOND threshold decision, taken on the
+    un-refined sigma (rem_pic.py:185-192) — ``att_gpu`` (the HIP plan's attention mask) is audited by the same rule, and a
+    slice with a (proven) attention-mask event counts as tainted: its refined (mu, sigma) legitimately differ."""
     ns = div // chunk
     sl = lambda t, i: t[:, i * chunk:(i + 1) * chunk]
     yg, yo = y_gpu.float().cpu(), ref["y"]
@@ -85,6 +89,23 @@ def audit(y_gpu: torch.Tensor, out: Dict[str, torch.Tensor], ref: Dict[str, torc
         if (nm or nsym) and rep["first"] is None:
             rep["first"] = f"prog {j}"
         tainted = any(flipped_b[k] for k in range(j + 1))
+        if "att" in ref and att_gpu is not None and not tainted:
+            adiff = sl(att_gpu, j) != sl(ref["att"], j)
+            if adiff.any():
+                rep.setdefault("att_flips", 0)
+                rep["att_flips"] += int(adiff.sum())
+                sr = sl(ref["std_raw"], j)
+                for b in range(sr.shape[0]):
+                    if not adiff[b].any():
+                        continue
+                    thr = float(O.quantile_threshold_np(sr[b].numpy().ravel(), min(q, 10) * 0.1))
+                    sv = sr[b][adiff[b]]
+                    bad = (sv - thr).abs() >= THRESH_TOL * torch.clamp(sv.abs(), min=1.0)
+                    rep["explained"] += int(adiff[b].sum()) - int(bad.sum())
+                    if bad.any():
+                        rep["violations"].append(f"prog slice {j} image {b}: {int(bad.sum())} differing REM attention-mask bits are "
+                                                 f"NOT threshold events of the un-refined sigma (thr {thr:.6g})")
+                tainted = True                      # the refined entropy parameters of this slice follow the attention mask
         if not all_scalable:          # pic.py:586-587: the (mu, sigma) stacks read the decoded progressive slices before j
             tainted = tainted or prog_flipped
             prog_flipped = prog_flipped or bool(nm or nsym)

@@ -19,11 +19,15 @@ from parity_audit import audit     # noqa: E402
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _latent(net, B, H, W, base_only, rem_idx):
+def _plan(net, B, H, W, base_only, rem_idx):
     for k, p in net._plans.items():
         if k[:5] == (B, H, W, base_only, rem_idx) and len(k) == 6:
-            return p.y.torch_nchw().cpu()
+            return p
     raise KeyError
+
+
+def _latent(net, B, H, W, base_only, rem_idx):
+    return _plan(net, B, H, W, base_only, rem_idx).y.torch_nchw().cpu()
 
 
 @pytest.mark.parametrize("name", list(CONFIG_VARIANTS))
@@ -49,10 +53,10 @@ def test_config_variant_matches_reference(name):
         ref = O.forward_single_quality(sd, x, q, checkpoint_ref=ck if use_ck else None, **kw)
         cpu = {k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}
         rem_idx = 0 if use_ck else None
+        att = _plan(net, 1, 64, 64, q == 0, rem_idx).att.torch_nchw().cpu() if use_ck else None
         aud = audit(_latent(net, 1, 64, 64, q == 0, rem_idx), cpu, ref, q, all_scalable=a.all_scalable,
-                    delta_encode=a.delta_encode)
-        if not use_ck:                       # (with a REM the attention mask is a second, unaudited threshold decision)
-            assert aud["violations"] == [], (tag, aud)
+                    delta_encode=a.delta_encode, att_gpu=att)
+        assert aud["violations"] == [], (tag, aud)      # REM variants too: the attention mask is audited by the same rule
         if aud["sym_flips"] == 0 and aud["mask_flips"] == 0:
             assert (cpu["y_hat"] - torch.from_numpy(gold[tag + "_y_hat"])).abs().max().item() <= 2e-4 * 60, tag
             # The synthetic weights of the single-encoder / single-decoder variants drive g_s far into the clamp (most
@@ -66,7 +70,8 @@ def test_config_variant_matches_reference(name):
             mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= p_tol, (tag, saturated)
             bpp = -cpu["log2_likelihood_sum"].sum().item() / 4096
-            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
+            print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
+            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])       # ABSOLUTE (north star)
         else:
             print("boundary hit", tag, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
             assert aud["sym_flips"] <= 0.05 * cpu["y_hat"].numel()

@@ -14,9 +14,24 @@ import vampic                    # noqa: E402
 import vampic_oracle as O        # noqa: E402
 
 
-@pytest.mark.parametrize("shape,q", [((32, 256, 256), 2.5), ((8, 512, 768), 0.75), ((32, 256, 256), 9.99)])
-def test_full_size_stagewise(gpu_model, shape, q):
+def _rms_rel(got, ref):
+    return float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("shape,q,storage", [((32, 256, 256), 2.5, "fp32"), ((8, 512, 768), 0.75, "fp32"), ((32, 256, 256), 9.99, "fp32"),
+                                             ((8, 512, 768), 0.75, "bf16")])
+def test_full_size_stagewise(gpu_model, shape, q, storage):
+    """``storage = "bf16"`` is BASELINE configs[2] as named (Kodak shape, batch 8, bf16): every fp32 stage of that plan —
+    variance mask, quantisation, likelihoods, in-kernel bpp, hyperprior and all entropy-parameter / LRP stacks — is held
+    to the SAME bounds as in the fp32 configuration, on the bf16 plan's own inputs; the bf16-stored transforms g_a / g_s
+    are compared with the oracle's emulation of the same rounding points (O.bf16_storage: both sides round at bf16
+    boundaries, single elements may sit an ulp apart: 2 % of the rms)."""
     net, sd = gpu_model
+    bf16 = storage == "bf16"
+    if bf16:
+        import copy
+        net = copy.deepcopy(net)
+        net.storage = "bf16"
     B, H, W = shape
     x = vampic.synth.synth_image(B, H, W, seed=11).cuda()
     with torch.no_grad():
@@ -53,8 +68,13 @@ def test_full_size_stagewise(gpu_model, shape, q):
     sup = torch.cat([ref_m, cpu["y_base"][sel][:, :32]], 1)
     ref_mu0 = O.cc_stack(sd, "cc_mean_transforms_prog.0.", sup)
     assert (mu[sel][:, :32] - ref_mu0).abs().max().item() <= 3e-4 * max(1.0, ref_mu0.abs().max().item())
-    ref_x = O.g_s(sd, "g_s.1.", cpu["y_hat"][sel]).clamp(0, 1)
-    assert (cpu["x_hat"][sel] - ref_x).abs().max().item() <= 1e-4
+    if bf16:
+        with O.bf16_storage():
+            ref_x = O.g_s(sd, "g_s.1.", cpu["y_hat"][sel]).clamp(0, 1)
+        assert _rms_rel(cpu["x_hat"][sel], ref_x) <= 2e-2
+    else:
+        ref_x = O.g_s(sd, "g_s.1.", cpu["y_hat"][sel]).clamp(0, 1)
+        assert (cpu["x_hat"][sel] - ref_x).abs().max().item() <= 1e-4
     assert cpu["x_hat"].min() >= 0 and cpu["x_hat"].max() <= 1
     # (4b) EVERY conv family at full size, teacher-forced on the GPU's own inputs (images 0 and last):
     #      g_a (both encoders), h_a, the four hyper-synthesis stacks, a base mean / scale / LRP stack, a progressive
@@ -64,8 +84,12 @@ def test_full_size_stagewise(gpu_model, shape, q):
         assert err <= tol * max(1.0, ref.abs().max().item()), (what, err, ref.abs().max().item())
     xs = x.cpu()[sel]
     ys = y[sel]
-    close(ys[:, :320], O.g_a(sd, "g_a.0.", xs), 1e-4, "g_a.0")
-    close(ys[:, 320:], O.g_a(sd, "g_a.1.", xs), 1e-4, "g_a.1")
+    if bf16:
+        with O.bf16_storage():
+            assert _rms_rel(ys[:, :320], O.g_a(sd, "g_a.0.", xs)) <= 2e-2 and _rms_rel(ys[:, 320:], O.g_a(sd, "g_a.1.", xs)) <= 2e-2
+    else:
+        close(ys[:, :320], O.g_a(sd, "g_a.0.", xs), 1e-4, "g_a.0")
+        close(ys[:, 320:], O.g_a(sd, "g_a.1.", xs), 1e-4, "g_a.1")
     close(plan.z.torch_nchw().cpu()[sel], O.h_a(sd, ys), 1e-4, "h_a")
     mh, sh = plan.means_h.torch_nchw().cpu()[sel], plan.scales_h.torch_nchw().cpu()[sel]
     for k in (0, 1):

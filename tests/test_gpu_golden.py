@@ -66,8 +66,9 @@ def _check_against_vectors(tag, x, o, gold, scal, n_pix, net=None, sd=None, q=No
         if scal is not None:
             mse = torch.nn.functional.mse_loss(x, o["x_hat"].cpu()).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
-            bpp = -o["log2_likelihood_sum"].sum().item() / n_pix
-            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
+            bpp = -o["log2_likelihood_sum"].sum().item() / n_pix          # double in-kernel sum vs the reference's float64 sum
+            print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
+            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])   # ABSOLUTE (north star)
         return True
     print("boundary hit", tag, flips, None if aud is None else {k: aud[k] for k in ("first", "explained", "downstream")})
     assert flips <= 0.02 * ref_y.numel() and x_err <= 0.5, (tag, flips, x_err)
@@ -92,7 +93,7 @@ def test_forward_matches_reference_vectors(gpu_model):
     clean += _check_against_vectors("rem", x, o, gold, None, 8192)
     total += 1
     print(f"reference vectors reproduced in every rounding decision: {clean}/{total}")
-    assert clean >= 0.85 * total, f"only {clean}/{total} reference vectors reproduced in every rounding decision"
+    assert clean >= 0.9 * total, f"only {clean}/{total} reference vectors reproduced in every rounding decision"
 
 
 # ---- BASELINE configs[0]: the demo's workload, one 256x256 image (reference demo.py / test/parser.py:20 q_levs)
@@ -137,9 +138,10 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
         assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
         bpp = -cpu["log2_likelihood_sum"].sum().item() / 65536
-        assert abs(bpp - scal[tag]["bpp"]) <= 1e-6 * max(1.0, scal[tag]["bpp"]), (tag, bpp, scal[tag]["bpp"])
+        print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
+        assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])           # ABSOLUTE (north star)
     print(f"256x256 demo image: {clean}/{total} quality levels reproduced in every rounding decision")
-    assert clean >= 0.8 * total
+    assert clean >= 0.9 * total
 
 
 def _thresholds(net, B, H, W):

@@ -42,6 +42,8 @@ def _cmp(out, ref, B, H, W, q):
 SHAPES = [(1, 64, 64), (1, 64, 128), (1, 128, 128)]
 QS = [0, 0.5, 2.5, 10]
 MIN_CLEAN_FRACTION = 0.9
+BPP_ABS_TOL = 1e-6          # absolute, on difference-free cases, for the double-precision in-kernel rate sum
+_BPP_ABS = []
 
 
 def _one_case(net, sd, shape, seed, q):
@@ -62,7 +64,10 @@ def _one_case(net, sd, shape, seed, q):
         assert abs(psnr_g - psnr_r) <= 1e-4, (shape, seed, q, psnr_g, psnr_r)          # dB
         tol = 1e-6 * max(1.0, rep["bpp_ref"])
         assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
-        assert abs(rep["bpp_kernel"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
+        # the in-kernel sum is double (log2 of each fp32 likelihood accumulated in float64): against the float64 sum over
+        # the ORACLE's likelihoods the north star's ABSOLUTE 1e-6 bpp is asked of it (BPP_ABS_TOL, measured maxima printed)
+        _BPP_ABS.append(abs(rep["bpp_kernel"] - rep["bpp_ref"]))
+        assert _BPP_ABS[-1] <= BPP_ABS_TOL, (shape, seed, q, rep)
         for k in ("y_hat", "mu_base", "std_base"):
             a, b = out[k].cpu(), ref[k]
             assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), (shape, seed, q, k)
@@ -86,7 +91,7 @@ def test_forward_single_quality_parity(gpu_model):
                 clean += ok
                 total += 1
         per_shape[shape] = c
-    print(f"difference-free cases: {clean}/{total}  per shape {per_shape}")
+    print(f"difference-free cases: {clean}/{total}  per shape {per_shape};  max |bpp_kernel - bpp_oracle| over them: {max(_BPP_ABS):.3e} (absolute)")
     assert clean >= MIN_CLEAN_FRACTION * total, f"only {clean}/{total} cases agree in every rounding decision: {per_shape}"
 
 
