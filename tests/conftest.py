@@ -47,3 +47,25 @@ def gpu_model(synth_model_cpu):
     import copy
     g = copy.deepcopy(net).to("cuda").eval()
     return g, sd
+
+
+# Rate parity of the double-precision in-kernel sum (log2 of each fp32 likelihood accumulated in float64) against a
+# float64 sum over the oracle's / the reference's likelihoods, on cases without a differing rounding decision.  The
+# north star asks |dbpp| <= 1e-6 ABSOLUTE.  Measured (r03, MI355X, synthetic weights = 20-25 bpp, 40x a trained codec's
+# rate): 1e-8 ... 7e-7 in ~85 % of the cases, 1.9e-6 at worst (8e-8 of the rate: single likelihoods near the 1e-9 bound
+# differ in their last fp32 bits between erfc implementations).  So: every case within 2.5e-6 absolute (the previous
+# bound was 1e-6 RELATIVE = 2.2e-5 here), and most cases within the north star's 1e-6.
+BPP_ABS_TOL = 2.5e-6
+BPP_ABS_TARGET = 1e-6
+BPP_ABS_SEEN = []
+
+
+def check_bpp_abs(got: float, want: float, what=""):
+    d = abs(got - want)
+    BPP_ABS_SEEN.append(d)
+    assert d <= BPP_ABS_TOL, (what, got, want, d)
+    return d
+
+
+def bpp_target_fraction() -> float:
+    return sum(d <= BPP_ABS_TARGET for d in BPP_ABS_SEEN) / max(len(BPP_ABS_SEEN), 1)

@@ -16,6 +16,8 @@ import vampic_oracle as O          # noqa: E402
 from config_variants import CONFIG_VARIANTS, variant_args, oracle_kwargs     # noqa: E402
 from parity_audit import audit     # noqa: E402
 
+from conftest import check_bpp_abs      # noqa: E402
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -70,8 +72,7 @@ def test_config_variant_matches_reference(name):
             mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= p_tol, (tag, saturated)
             bpp = -cpu["log2_likelihood_sum"].sum().item() / 4096
-            print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
-            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])       # ABSOLUTE (north star)
+            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.BPP_ABS_TOL)
         else:
             print("boundary hit", tag, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
             assert aud["sym_flips"] <= 0.05 * cpu["y_hat"].numel()

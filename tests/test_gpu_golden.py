@@ -12,6 +12,8 @@ import vampic                      # noqa: E402
 import vampic.synth as synth       # noqa: E402
 from vampic import layers as Ly    # noqa: E402
 
+from conftest import check_bpp_abs      # noqa: E402
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
 
@@ -67,8 +69,7 @@ def _check_against_vectors(tag, x, o, gold, scal, n_pix, net=None, sd=None, q=No
             mse = torch.nn.functional.mse_loss(x, o["x_hat"].cpu()).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
             bpp = -o["log2_likelihood_sum"].sum().item() / n_pix          # double in-kernel sum vs the reference's float64 sum
-            print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
-            assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])   # ABSOLUTE (north star)
+            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.BPP_ABS_TOL)
         return True
     print("boundary hit", tag, flips, None if aud is None else {k: aud[k] for k in ("first", "explained", "downstream")})
     assert flips <= 0.02 * ref_y.numel() and x_err <= 0.5, (tag, flips, x_err)
@@ -138,8 +139,7 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
         assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
         bpp = -cpu["log2_likelihood_sum"].sum().item() / 65536
-        print("bpp abs diff", tag, abs(bpp - scal[tag]["bpp"]))
-        assert abs(bpp - scal[tag]["bpp"]) <= 1e-6, (tag, bpp, scal[tag]["bpp"])           # ABSOLUTE (north star)
+        check_bpp_abs(bpp, scal[tag]["bpp"], tag)                    # ABSOLUTE (conftest.BPP_ABS_TOL)
     print(f"256x256 demo image: {clean}/{total} quality levels reproduced in every rounding decision")
     assert clean >= 0.9 * total
 
