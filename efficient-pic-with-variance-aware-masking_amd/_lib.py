@@ -78,6 +78,13 @@ class VamConv(C.Structure):
     ]
 
 
+class VamResunit(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_int32), ("ldo", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "vam_last_error": (C.c_char_p, []),
@@ -95,6 +102,11 @@ _SIGNATURES = {
     "vam_conv_set_mode": (C.c_int, [C.c_int]),
     "vam_conv_get_mode": (C.c_int, []),
     "vam_conv_group": (C.c_int, [C.POINTER(VamConv), C.c_int, C.c_void_p]),
+    "vam_resunit_struct_size": (C.c_size_t, []),
+    "vam_resunit_supported": (C.c_int, [C.c_int] * 3),
+    "vam_resunit_group": (C.c_int, [C.POINTER(VamResunit), C.c_int, C.c_void_p]),
+    "vam_resunit_set_dma": (C.c_int, [C.c_int]),
+    "vam_resunit_set_debug": (C.c_int, [C.c_void_p]),
     "vam_s2d_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -168,6 +180,8 @@ def load():
         fn.argtypes = args
     if lib.vam_conv_struct_size() != C.sizeof(VamConv):
         raise VamError(f"ABI mismatch: sizeof(vam_conv) is {lib.vam_conv_struct_size()} in libvampic.so, {C.sizeof(VamConv)} in the binding")
+    if lib.vam_resunit_struct_size() != C.sizeof(VamResunit):
+        raise VamError(f"ABI mismatch: sizeof(vam_resunit) is {lib.vam_resunit_struct_size()} in libvampic.so, {C.sizeof(VamResunit)} in the binding")
     _lib = lib
     return lib
 

@@ -95,6 +95,22 @@ class Plan:
             self.class_of.append(self.cur_class)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
+    def resunit(self, problems: Sequence["L.VamResunit"]):
+        """Fused residual units (one launch per group of up to VAM_MAX_GROUP units, csrc/resunit.hip)."""
+        lib = L.load()
+        for i in range(0, len(problems), L.VAM_MAX_GROUP):
+            chunk = list(problems[i:i + L.VAM_MAX_GROUP])
+            arr = (L.VamResunit * len(chunk))(*chunk)
+            n = len(chunk)
+            self.keep.append(arr)
+            fl = sum(2.0 * c.B * c.H * c.W * (c.C * (c.C // 2) * 2 + (c.C // 2) ** 2 * 9) for c in chunk)
+            self.flops += fl
+            c0 = chunk[0]
+            self.meta.append({"kind": "conv", "flops": fl, "desc": f"{n}x[resunit {c0.C} P={c0.B * c0.H * c0.W}]"})
+            self.branch_of.append(self.cur_branch)
+            self.class_of.append(self.cur_class)
+            self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_resunit_group(arr, n, ops.stream_ptr()), "vam_resunit_group"))
+
     def wgrad(self, problems: Sequence[L.VamWgrad]):
         """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`)."""
         lib = L.load()
@@ -338,7 +354,14 @@ def lower_gdn(plan: Plan, mods: Sequence[Ly.GDN], xs: Sequence[View], outs: Sequ
 
 
 def lower_residual_units(plan: Plan, mods: Sequence[Ly.ResidualUnit], xs: Sequence[View]) -> List[View]:
-    """out = GELU(conv(x) + x)  (layers/layers.py:43-48), K units in lockstep."""
+    """out = GELU(conv(x) + x)  (layers/layers.py:43-48), K units in lockstep.  Shapes with a fused kernel
+    (csrc/resunit.hip) take ONE launch per group of units, both C/2-channel intermediates staying in LDS; the rest
+    run as three grouped conv launches — the same arithmetic, bit for bit."""
+    if all(ops.resunit_supported(x) for x in xs) and not plan.act16:
+        outs = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
+        plan.resunit([ops.resunit_problem(m.conv[0].packed(), m.conv[2].packed(), m.conv[4].packed(), x, o)
+                      for m, x, o in zip(mods, xs, outs)])
+        return outs
     fin = [dict(act=L.ACT_GELU, pre=x) for x in xs]
     return lower_stacks(plan, [m.conv for m in mods], [[x] for x in xs], [None] * len(mods), fin)
 

@@ -7,6 +7,7 @@ every arithmetic op below is a libvampic call.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -353,6 +354,41 @@ def conv_group(problems: Sequence[L.VamConv]):
         chunk = problems[i:i + L.VAM_MAX_GROUP]
         arr = (L.VamConv * len(chunk))(*chunk)
         L.check(lib.vam_conv_group(arr, len(chunk), s), "vam_conv_group")
+
+
+# --------------------------------------------------------------------------- fused residual unit
+def resunit_supported(x: View) -> bool:
+    """A fused kernel exists for this unit's shape (csrc/resunit.hip: fp32 tensors, split-operand mode, C = 192)."""
+    if type(x) is not View or not split_mode() or os.environ.get("VAMPIC_FUSED_RU", "1") == "0":
+        return False
+    return bool(L.load().vam_resunit_supported(x.C, x.H, x.W))
+
+
+def resunit_problem(p1: Packed, p2: Packed, p3: Packed, x: View, out: View) -> "L.VamResunit":
+    """One ResidualUnit (layers/layers.py:30-48) as a single launch; p1 / p2 / p3 are the ordinary packed weights of
+    its 1x1 (C -> C/2), 3x3 (C/2 -> C/2) and 1x1 (C/2 -> C) convolutions."""
+    assert type(x) is View and type(out) is View, "the fused residual unit reads and writes fp32 NHWC tensors"
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    C_ = x.C
+    assert (p1.kh, p1.cin, p1.n) == (1, C_, C_ // 2) and (p2.kh, p2.kw, p2.cin, p2.n, p2.stride) == (3, 3, C_ // 2, C_ // 2, 1) and \
+        (p3.kh, p3.cin, p3.n) == (1, C_ // 2, C_), "residual unit: conv1x1(C, C/2), conv3x3(C/2, C/2), conv1x1(C/2, C)"
+    assert not (p1.w16 or p2.w16 or p3.w16) and p1.b is not None and p2.b is not None and p3.b is not None
+    c = L.VamResunit()
+    c.x, c.out, c.ldx, c.ldo = x.ptr, out.ptr, x.ld, out.ld
+    c.B, c.H, c.W, c.C = x.B, x.H, x.W, C_
+    c.w1, c.b1 = p1.w.data_ptr(), p1.b.data_ptr()
+    c.w2, c.b2 = p2.w.data_ptr(), p2.b.data_ptr()
+    c.w3, c.b3 = p3.w.data_ptr(), p3.b.data_ptr()
+    return c
+
+
+def resunit_group(problems: Sequence["L.VamResunit"]):
+    lib = L.load()
+    s = stream_ptr()
+    for i in range(0, len(problems), L.VAM_MAX_GROUP):
+        chunk = problems[i:i + L.VAM_MAX_GROUP]
+        arr = (L.VamResunit * len(chunk))(*chunk)
+        L.check(lib.vam_resunit_group(arr, len(chunk), s), "vam_resunit_group")
 
 
 # --------------------------------------------------------------------------- other ops

@@ -165,6 +165,34 @@ int vam_conv_get_mode(void);
 /* Diagnostics: the (BM, BN, BK) the tile heuristic picked for the most recent vam_conv_group launch. */
 int vam_conv_last_tile(int* bm, int* bn, int* bk);
 
+/* ------------------------------------------------------------------ fused residual unit */
+/*
+ * One ResidualUnit (reference layers/layers.py:30-48) as ONE launch:
+ *   out = GELU( x + conv1x1(GELU(conv3x3(GELU(conv1x1(x))))) )
+ * with both C/2-channel intermediates kept in LDS (csrc/resunit.hip).  The weights are the three convolutions'
+ * ordinary packed weights (vam_pack_conv_weights, VAM_PACK_CONV, split-operand mode) and biases; results are
+ * bit-identical to three vam_conv_group launches.  Built for C = 192 (the 64x64-position attention blocks of
+ * g_a / g_s); vam_resunit_supported says whether a shape has a fused kernel — callers fall back to three
+ * vam_conv_group launches (the same arithmetic) where it does not.
+ */
+typedef struct vam_resunit {
+  const float* x;           /* input and identity, NHWC fp32 */
+  float* out;               /* NHWC fp32, must not alias x   */
+  int32_t ldx, ldo;         /* pixel strides (floats)        */
+  int32_t B, H, W, C;
+  const float* w1; const float* b1;   /* conv[0]: 1x1 C   -> C/2 */
+  const float* w2; const float* b2;   /* conv[2]: 3x3 C/2 -> C/2 */
+  const float* w3; const float* b3;   /* conv[4]: 1x1 C/2 -> C   */
+} vam_resunit;
+size_t vam_resunit_struct_size(void);
+int vam_resunit_supported(int C, int H, int W);
+int vam_resunit_group(const vam_resunit* problems, int n_problems, void* stream);
+/* Measurement hook: 1 (default) = weight slabs by LDS-DMA through a three-slot ring, 0 = register-staged. */
+int vam_resunit_set_dma(int on);
+/* Measurement hook: device buffer receiving 8 cycle-counter stamps per workgroup at the kernel's phase boundaries
+ * (scratch/ru_phases.py); NULL (default) = off. */
+int vam_resunit_set_debug(void* stamps);
+
 /* ------------------------------------------------------------------ model edges */
 /* x NCHW [B,3,H,W] -> space-to-depth NHWC [B,H/2,W/2,16] (12 real channels (py,px,c), 4 zero)
  * so that conv5x5 s2 (3->N) becomes a 3x3 s1 MFMA problem (layers/layers.py:5-12, builder.py:44). */

@@ -72,7 +72,7 @@ def test_config_variant_matches_reference(name):
             mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= p_tol, (tag, saturated)
             bpp = -cpu["log2_likelihood_sum"].sum().item() / 4096
-            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.BPP_ABS_TOL)
+            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.bpp_tol: max(1e-6, 4 fp32 ulps of the rate))
         else:
             print("boundary hit", tag, {k: aud[k] for k in ("first", "sym_flips", "mask_flips", "explained", "downstream")})
             assert aud["sym_flips"] <= 0.05 * cpu["y_hat"].numel()

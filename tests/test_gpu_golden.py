@@ -69,7 +69,7 @@ def _check_against_vectors(tag, x, o, gold, scal, n_pix, net=None, sd=None, q=No
             mse = torch.nn.functional.mse_loss(x, o["x_hat"].cpu()).item()
             assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
             bpp = -o["log2_likelihood_sum"].sum().item() / n_pix          # double in-kernel sum vs the reference's float64 sum
-            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.BPP_ABS_TOL)
+            check_bpp_abs(bpp, scal[tag]["bpp"], tag)                # ABSOLUTE (conftest.bpp_tol: max(1e-6, 4 fp32 ulps of the rate))
         return True
     print("boundary hit", tag, flips, None if aud is None else {k: aud[k] for k in ("first", "explained", "downstream")})
     assert flips <= 0.02 * ref_y.numel() and x_err <= 0.5, (tag, flips, x_err)
@@ -139,7 +139,7 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         mse = torch.nn.functional.mse_loss(x, cpu["x_hat"]).item()
         assert abs(-10 * np.log10(mse) - scal[tag]["psnr"]) <= 1e-4, tag
         bpp = -cpu["log2_likelihood_sum"].sum().item() / 65536
-        check_bpp_abs(bpp, scal[tag]["bpp"], tag)                    # ABSOLUTE (conftest.BPP_ABS_TOL)
+        check_bpp_abs(bpp, scal[tag]["bpp"], tag)                    # ABSOLUTE (conftest.bpp_tol: max(1e-6, 4 fp32 ulps of the rate))
     print(f"256x256 demo image: {clean}/{total} quality levels reproduced in every rounding decision")
     assert clean >= 0.9 * total
 

@@ -65,7 +65,7 @@ def _one_case(net, sd, shape, seed, q):
         tol = 1e-6 * max(1.0, rep["bpp_ref"])
         assert abs(rep["bpp_gpu"] - rep["bpp_ref"]) <= tol, (shape, seed, q, rep)
         # the in-kernel sum is double (log2 of each fp32 likelihood accumulated in float64): against the float64 sum over
-        # the ORACLE's likelihoods the north star's ABSOLUTE 1e-6 bpp is asked of it (BPP_ABS_TOL, measured maxima printed)
+        # the ORACLE's likelihoods the north star's ABSOLUTE 1e-6 bpp is asked of it (conftest.bpp_tol, measured maxima printed)
         _BPP_ABS.append(check_bpp_abs(rep["bpp_kernel"], rep["bpp_ref"], (shape, seed, q)))
         for k in ("y_hat", "mu_base", "std_base"):
             a, b = out[k].cpu(), ref[k]

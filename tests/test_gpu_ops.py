@@ -231,6 +231,41 @@ def test_conv_result_is_independent_of_tiling():
             assert torch.equal(o, outs[0]), (cin, n, k, st)
 
 
+@pytest.mark.parametrize("hw,batch", [((16, 16), 2), ((24, 40), 2), ((13, 21), 1), ((64, 64), 2), ((8, 16), 3)])
+def test_fused_residual_unit_is_bit_identical(hw, batch, monkeypatch):
+    """csrc/resunit.hip runs a ResidualUnit (layers/layers.py:30-48) as ONE launch with both C/2-channel intermediates
+    in LDS.  Same split-operand arithmetic in the same canonical K order as three conv launches: the results must agree
+    bit for bit (image sizes that are not multiples of the 8 x 16 tile included), with the weight slabs staged by LDS-DMA
+    and by registers alike; and both agree with the oracle's fp32 unit."""
+    lib = L.load()
+    m = Ly.ResidualUnit(192)
+    sd = _fill(m, 31)
+    x = _rand((batch, 192) + hw, 32)
+    m = m.cuda()
+    xc = x.cuda()
+    assert ops.resunit_supported(ops.from_nchw(xc)), "C = 192 has a fused kernel"
+    outs = {}
+    with torch.no_grad():
+        for dma in (1, 0):
+            lib.vam_resunit_set_dma(dma)
+            try:
+                outs[f"fused dma={dma}"] = m(xc).clone()
+            finally:
+                lib.vam_resunit_set_dma(1)
+        monkeypatch.setenv("VAMPIC_FUSED_RU", "0")
+        assert not ops.resunit_supported(ops.from_nchw(xc))
+        outs["three launches"] = m(xc).clone()
+        monkeypatch.delenv("VAMPIC_FUSED_RU")
+    ref3 = outs["three launches"]
+    for k, o in outs.items():
+        assert torch.isfinite(o).all(), k
+        assert torch.equal(o, ref3), f"{k}: {(o != ref3).sum().item()} of {o.numel()} elements differ, max {(o - ref3).abs().max().item():.3e}"
+    t = F.gelu(F.conv2d(x, sd["conv.0.weight"], sd["conv.0.bias"]))
+    t = F.gelu(F.conv2d(t, sd["conv.2.weight"], sd["conv.2.bias"], padding=1))
+    ref = F.gelu(F.conv2d(t, sd["conv.4.weight"], sd["conv.4.bias"]) + x)
+    _close(ref3, ref, what="residual unit vs ATen fp32")
+
+
 def test_direct_and_staged_epilogues_are_bit_identical():
     """On the 128x64 tile fp32 NHWC outputs leave the convolution kernel straight from the accumulator registers (direct
     epilogue); every other tile, bf16 / plane / NCHW outputs and tensors beyond its 32-bit window go through LDS
