@@ -231,12 +231,13 @@ def test_conv_result_is_independent_of_tiling():
             assert torch.equal(o, outs[0]), (cin, n, k, st)
 
 
-@pytest.mark.parametrize("hw,batch", [((16, 16), 2), ((24, 40), 2), ((13, 21), 1), ((64, 64), 2), ((8, 16), 3)])
+@pytest.mark.parametrize("hw,batch", [((16, 16), 2), ((24, 40), 2), ((13, 21), 1), ((64, 64), 2), ((8, 16), 3), ((64, 64), 40)])
 def test_fused_residual_unit_is_bit_identical(hw, batch, monkeypatch):
     """csrc/resunit.hip runs a ResidualUnit (layers/layers.py:30-48) as ONE launch with both C/2-channel intermediates
     in LDS.  Same split-operand arithmetic in the same canonical K order as three conv launches: the results must agree
-    bit for bit (image sizes that are not multiples of the 8 x 16 tile included), with the weight slabs staged by LDS-DMA
-    and by registers alike; and both agree with the oracle's fp32 unit."""
+    bit for bit (image sizes that are not multiples of the 8 x 16 tile included) in all three variants of the kernel — the
+    persistent one with the deferred epilogue, and the one-tile-per-workgroup arms with the weight slabs staged by
+    LDS-DMA and by registers; and they agree with ATen's fp32 unit."""
     lib = L.load()
     m = Ly.ResidualUnit(192)
     sd = _fill(m, 31)
@@ -246,12 +247,12 @@ def test_fused_residual_unit_is_bit_identical(hw, batch, monkeypatch):
     assert ops.resunit_supported(ops.from_nchw(xc)), "C = 192 has a fused kernel"
     outs = {}
     with torch.no_grad():
-        for dma in (1, 0):
-            lib.vam_resunit_set_dma(dma)
+        for mode in (2, 1, 0):        # persistent kernel (default) / one tile per workgroup with the LDS-DMA ring / register-staged
+            lib.vam_resunit_set_dma(mode)
             try:
-                outs[f"fused dma={dma}"] = m(xc).clone()
+                outs[f"fused mode={mode}"] = m(xc).clone()
             finally:
-                lib.vam_resunit_set_dma(1)
+                lib.vam_resunit_set_dma(-1)
         monkeypatch.setenv("VAMPIC_FUSED_RU", "0")
         assert not ops.resunit_supported(ops.from_nchw(xc))
         outs["three launches"] = m(xc).clone()
