@@ -28,9 +28,19 @@
 // ds_write; the XOR swizzle of the LDS image is applied to the per-lane SOURCE address), two slabs ahead of the
 // MFMAs, one raw s_barrier per slab behind a counted s_waitcnt vmcnt.  Only x (fp32 in HBM) is staged through
 // registers, because it has to be split.  12 waves per workgroup (3 per SIMD): GEMM2's 12 (channel tile, pixel tile)
-// pairs are one per wave.  LDS: 180 x 576 B of planes + 3 x 18 KB = 155 KB, one workgroup per CU.
+// pairs are one per wave; its operand fragments are double-buffered in registers (the LDS reads of slab k+1 are in flight
+// under the MFMAs of slab k: 51.5k -> 41.7k cycles for the 27 slabs).  LDS: 180 x 576 B of planes + 3 x 18 KB = 155 KB,
+// one workgroup per CU.
+//
+// Where a tile's 110k cycles go (s_memtime stamps, scratch/ru_phases.py; matrix-pipe time alone would be 53k):
+// GEMM1 23.5k (x from HBM, 1.41x halo) | t1 conversion 12.9k | GEMM2 41.7k | t2 conversion 5.7k | GEMM3 10.0k |
+// epilogue 16.7k.  The conversion phases are vector-pipe bound (45 instructions per erff GELU, 54k of them per tile,
+// + the bf16x3 split) and, with one workgroup per CU, nothing runs beside them.  A persistent variant that deferred the
+// epilogue and two thirds of the t1 conversion into GEMM2's idle issue slots (one wave of each SIMD per slab, exact
+// compile-time s_waitcnt counts around the LDS-DMA ring) was built, is bit-identical and spill-free, and is NOT faster
+// (988 vs 955 us per four units: a lone wave issues vector instructions at half the pipe's rate and the slab waits for
+// it; git history, "experiment: persistent fused-ResidualUnit kernel").
 #include "common.h"
-#include <utility>
 
 namespace vam {
 
@@ -82,7 +92,7 @@ __device__ __forceinline__ void ru_split4(const float (&v)[4], uint2& h, uint2& 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], p[0], acc, 0, 0, 0);                 \
   } while (0)
 
-constexpr int RU_C = 192, RU_C2 = 96, RU_TH = 8, RU_TW = 16, RU_HW = RU_TW + 2, RU_NHALO = (RU_TH + 2) * (RU_TW + 2);
+constexpr int RU_C = 192, RU_TH = 8, RU_TW = 16, RU_HW = RU_TW + 2, RU_NHALO = (RU_TH + 2) * (RU_TW + 2);
 constexpr int RU_NT = 768;                       // 12 waves
 constexpr int RU_TROW = 576;                     // bytes of one t1 / t2 row: three 32-channel groups x 192 B
 constexpr int RU_TBYTES = RU_NHALO * RU_TROW;    // 103,680
@@ -538,480 +548,9 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
   stamp(6);
 }
 
-// ======================================================================================================================
-// Persistent variant (the default).  Phase stamps of the kernel above (scratch/ru_phases.py, cycles per 8 x 16 tile):
-// GEMM1 23.5k | t1 conversion 12.9k | GEMM2 41.7k | t2 conversion 5.7k | GEMM3 10.0k | epilogue 16.7k = 110k, against 53k
-// of matrix-pipe time: with one workgroup per CU (155 KB of LDS) nothing runs beside the GELU / split phases (~45 vector
-// instructions per erff, 54k of them per tile) and beside the load latency of GEMM1.  In GEMM2 every wave issues 12 MFMAs
-// per slab and then waits ~2/3 of the slab's time for its two SIMD partners and the barrier.  So this variant
-//  * walks its tiles in a loop (256 workgroups, every XCD's 32 walk that XCD's share of each problem);
-//  * DEFERS a tile's epilogue (+ x, GELU, store) into the idle issue slots of the NEXT tile's GEMM2 (eight slices per
-//    wave; the biased accumulators and the pixel's addresses stay in registers, each slice's identity is loaded one
-//    slice ahead);
-//  * defers two thirds of the t1 conversion the same way: GEMM2 walks the 32-channel groups of t1 in order, so only
-//    group 0 has to exist before slab 0; group 1 is converted during slabs 0..5, group 2 during slabs 9..14;
-//  * keeps the biases in LDS (no vector-memory instruction in the conversion phases).
-// GEMM2 is unrolled over its 27 slabs, so every s_waitcnt vmcnt count in front of a barrier is a compile-time constant
-// that counts the epilogue's loads and stores issued between the LDS-DMA instructions exactly.
-template <class F, int... I>
-__device__ __forceinline__ void ru_static_for(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-
-constexpr int RU_LDS_P = RU_LDS + (RU_C2 + RU_C2 + RU_C) * 4;   // + b1 | b2 | b3 = 160,512 B
-
-// Side-job schedule.  The three waves of a SIMD (rank = wid >> 2: waves w, w+4, w+8 share one) leave a barrier together;
-// if all three ran a side job behind their MFMAs the SIMD would alternate between a matrix phase and a vector phase
-// (measured: a slab with side jobs on every wave took 2,900 cycles instead of 1,540).  So in slab k only the wave of
-// rank k % 3 runs an epilogue slice (slice k / 3, eight slices per wave), while its two partners keep the matrix pipe
-// busy; the t1 slices sit in slabs that are not the wave's epilogue slabs.
-// vector-memory instructions of a rank-r wave in the side job of slab j: the store of slice j/3, then the identity load
-// of the next slice
-__host__ __device__ constexpr int ru_side_vmem(int j, int r) {
-  return (j >= 0 && j < 24 && j % 3 == r) ? 1 + (j / 3 + 1 < 8 ? 1 : 0) : 0;
-}
-// LDS-DMA instructions per wave issued at the top of slab j (slab j+3), j = -1: the prologue's slab 2
-__host__ __device__ constexpr int ru_dma_at(int j) { return j + 3 < 27 ? 2 : 0; }
-// outstanding instructions allowed at the barrier in front of slab k+1 (top of slab k): everything issued after the
-// LDS-DMA of slab k+1, which went out at the top of slab k-2
-__host__ __device__ constexpr int ru_vmcnt(int k, int r) {
-  return ru_side_vmem(k - 2, r) + ru_dma_at(k - 1) + ru_side_vmem(k - 1, r);
-}
-// 8-channel group (0..3) of the deferred t1 conversion a wave runs in slab k, or -1.  grp 1: waves 6..11 (ranks 1, 1,
-// 2, 2, 2, 2), needed from slab 9 on; grp 2: waves 0..5 (ranks 0, 0, 0, 0, 1, 1), needed from slab 18 on.
-__host__ __device__ constexpr int ru_t1_slot(int k, int grp, int r) {
-  if (grp == 1 && r == 1) return k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : -1;
-  if (grp == 1 && r == 2) return k == 0 ? 0 : k == 1 ? 1 : k == 3 ? 2 : k == 4 ? 3 : -1;
-  if (grp == 2 && r == 0) return k == 10 ? 0 : k == 11 ? 1 : k == 13 ? 2 : k == 14 ? 3 : -1;
-  if (grp == 2 && r == 1) return k == 9 ? 0 : k == 11 ? 1 : k == 12 ? 2 : k == 14 ? 3 : -1;
-  return -1;
-}
-
-template <int N>
-__device__ __forceinline__ void ru_bar() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
-__global__ __launch_bounds__(RU_NT, 3) void resunit192p_kernel(const RuArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sT = smem;
-  unsigned char* sR = smem + RU_TBYTES;
-  float* sBias = reinterpret_cast<float*>(smem + RU_LDS);   // b1 [96] | b2 [96] | b3 [192]
-
-  const int xcd = blockIdx.x & 7;
-  const int stride = (int)gridDim.x >> 3;
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  long long* const dbg = args.dbg;
-
-  auto desc = [&](const void* q) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
-    return __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
-                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)), 0, 0x7FFFFFFF, 0x00020000);
-  };
-
-  // ---- tile-independent per-thread roles (see the kernel above; GEMM1's staging roles are derived per tile from an
-  // opaque copy of the thread index, so that they do not occupy registers while GEMM2 / GEMM3 run)
-  unsigned dgo[2];
-  int dlo[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int j = wid * 2 + i;
-    j = j >= 18 ? j - 18 : j;
-    const int u = j * 64 + lane;
-    const int row = u / 12, cp = u - row * 12;
-    const int c = (cp & ~3) | ((cp & 3) ^ ((row >> 2) & 3));
-    dgo[i] = (unsigned)((row * 12 + c) * 16);
-    dlo[i] = j * 1024;
-  }
-  auto dma_slab = [&](const __amdgpu_buffer_rsrc_t& r, unsigned slab_byte, int slot) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(sR + slot * RU_SLOT + dlo[i]), 16,
-                                               (int)dgo[i], (int)slab_byte, 0, 0);
-  };
-  const int rsw = (l31 >> 2) & 3;
-  const int fsub[2] = {((lh ^ rsw) << 4), (((2 + lh) ^ rsw) << 4)};
-  const int px1 = wid < 6 ? wid : wid - 6;
-  // waves 0..5: channel tiles 0 (acc1[0]) and 2 (acc1[1]) of pixel tile wid; waves 6..11: channel tile 1 (acc1[1]) of pixel
-  // tile wid-6 — only acc1[1] is carried into GEMM2 (groups 1 and 2 of t1 are converted there)
-  const bool two1 = wid < 6;
-  const int c1b = two1 ? 2 : 1;
-  const int px2 = wid & 3, ct2 = wid >> 2;
-  const int hb2 = ((px2 * 32 + l31) >> 4) * RU_HW + (l31 & 15);
-  auto slab2 = [](int k) -> unsigned { const int g = k / 9, tap = k - g * 9; return (unsigned)((tap * 3 + g) * 96) * 192u; };
-  auto slab3 = [](int k) -> unsigned { return (unsigned)((k >> 1) * 192 + (k & 1) * 96) * 192u; };
-
-  // ---- the deferred epilogue of the previous tile: biased accumulators, byte offsets of this lane's pixel in that
-  // tile's x and out (2^31 = no pixel: the loads return zeros, the stores are dropped), the tensors' base addresses
-  f32x16 accP[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accP[q][r] = 0.f;
-  unsigned pend_xo = 0x80000000u, pend_oo = 0x80000000u;
-  const float* pend_x = args.p[0].x;
-  float* pend_out = args.p[0].out;
-  u32x4 xva;                                        // identity of the next epilogue slice
-  const int rank = wid >> 2;                        // position among the three waves of this wave's SIMD
-
-  // one slice (0..7) of the epilogue: channels (q*3 + ct2)*32 + 8j + 4lh .. +3 of this lane's pixel, q = s >> 2, j = s & 3
-  auto epi_slice = [&](int sl, const u32x4& xi, const __amdgpu_buffer_rsrc_t& r_o) {
-    const int q = sl >> 2, j = sl & 3;
-    const int ch = (q * 3 + ct2) * 32 + 8 * j + 4 * lh;
-    u32x4 o;
-    o.x = __float_as_uint(ru_gelu(accP[q][4 * j] + __uint_as_float(xi.x)));
-    o.y = __float_as_uint(ru_gelu(accP[q][4 * j + 1] + __uint_as_float(xi.y)));
-    o.z = __float_as_uint(ru_gelu(accP[q][4 * j + 2] + __uint_as_float(xi.z)));
-    o.w = __float_as_uint(ru_gelu(accP[q][4 * j + 3] + __uint_as_float(xi.w)));
-    __builtin_amdgcn_raw_buffer_store_b128(o, r_o, (int)(pend_oo + (unsigned)ch * 4u), 0, 0);
-  };
-  auto epi_load = [&](int sl, u32x4& xi, const __amdgpu_buffer_rsrc_t& r_i) {
-    const int q = sl >> 2, j = sl & 3;
-    xi = __builtin_amdgcn_raw_buffer_load_b128(r_i, (int)(pend_xo + (unsigned)(((q * 3 + ct2) * 32 + 8 * j + 4 * lh) * 4)), 0, 0);
-  };
-
-  int cur_pi = -1;
-  int iter = 0;
-  for (int idx0 = (int)blockIdx.x >> 3;; idx0 += stride, ++iter) {
-    // ---- which problem / tile (every XCD walks a contiguous eighth of each problem's tiles)
-    int pi = -1, t = 0;
-    {
-      int idx = idx0;
-#pragma unroll
-      for (int i = 0; i < VAM_MAX_GROUP; ++i) {
-        if (i < args.nprob && pi < 0) {
-          const int T = args.tile_start[i + 1] - args.tile_start[i];
-          const int q = T >> 3, r = T & 7;
-          const int c = q + (xcd < r ? 1 : 0);
-          if (idx < c) {
-            pi = i;
-            t = xcd * q + (xcd < r ? xcd : r) + idx;
-          } else {
-            idx -= c;
-          }
-        }
-      }
-    }
-    if (pi < 0) break;
-    const RuP& P = args.p[pi];
-    auto stamp = [&](int i) {
-      if (dbg != nullptr && tid == 0 && iter == 1) dbg[(size_t)blockIdx.x * 8 + i] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
-    if (pi != cur_pi) {                            // (block-uniform) this problem's biases -> LDS
-      __syncthreads();                             // the previous tile's last bias reads are done
-      if (tid < 96) sBias[tid] = P.b1[tid];
-      else if (tid < 192) sBias[tid] = P.b2[tid - 96];
-      else if (tid < 384) sBias[tid] = P.b3[tid - 192];
-      cur_pi = pi;                                 // (visible behind GEMM1's barriers)
-    }
-    const int u_H = __builtin_amdgcn_readfirstlane(P.H), u_W = __builtin_amdgcn_readfirstlane(P.W);
-    const int u_ldx = __builtin_amdgcn_readfirstlane(P.ldx), u_ldo = __builtin_amdgcn_readfirstlane(P.ldo);
-    const int tpi = P.tiles_x * P.tiles_y;
-    const int img = t / tpi;
-    const int tr = t - img * tpi;
-    const int tyi = tr / P.tiles_x;
-    const int y0 = tyi * RU_TH, x0 = (tr - tyi * P.tiles_x) * RU_TW;
-    int tid_t = tid;
-    asm volatile("" : "+v"(tid_t));
-    const int xrow = tid_t >> 2, xg = tid_t & 3;
-    const int xhy = xrow / RU_HW, xhx = xrow - xhy * RU_HW;
-    const int xst = xrow * 192 + ((xg ^ ((xrow >> 2) & 3)) << 4);
-    unsigned wgo[2];
-    int wlo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = tid_t + i * RU_NT;
-      const int row = u / 12, c = u - row * 12;
-      const bool ok = u < 96 * 12;
-      wgo[i] = ok ? (unsigned)(u * 16) : 0x80000000u;
-      wlo[i] = ok ? row * 192 + (((c & ~3) | ((c & 3) ^ ((row >> 2) & 3))) << 4) : -1;
-    }
-    unsigned xoff;
-    {
-      const int iy = y0 - 1 + xhy, ix = x0 - 1 + xhx;
-      const bool in = xrow < RU_NHALO && (unsigned)iy < (unsigned)u_H && (unsigned)ix < (unsigned)u_W;
-      xoff = in ? (unsigned)(((img * u_H + iy) * u_W + ix) * u_ldx * 4 + xg * 32) : 0x80000000u;
-    }
-
-    // =============================================================== GEMM1 (register-staged, compiler-managed waits)
-    f32x16 acc1[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[q][r] = 0.f;
-    {
-      const __amdgpu_buffer_rsrc_t r_x = desc(P.x), r_w1 = desc(P.w1);
-      u32x4 xr0[2], xr1[2], wr0[2], wr1[2];
-      auto gload1 = [&](int k, u32x4 (&xr)[2], u32x4 (&wr)[2]) {
-        xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(xoff + (unsigned)k * 128u), 0, 0);
-        xr[1] = __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(xoff + (unsigned)k * 128u + 16u), 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(r_w1, (int)(wgo[i] + (unsigned)k * (unsigned)RU_SLOT), 0, 0);
-      };
-      auto sstore1 = [&](int buf, const u32x4 (&xr)[2], const u32x4 (&wr)[2]) {
-        const float lo4[4] = {__uint_as_float(xr[0].x), __uint_as_float(xr[0].y), __uint_as_float(xr[0].z), __uint_as_float(xr[0].w)};
-        const float hi4[4] = {__uint_as_float(xr[1].x), __uint_as_float(xr[1].y), __uint_as_float(xr[1].z), __uint_as_float(xr[1].w)};
-        uint2 h0, m0, l0, h1, m1, l1;
-        ru_split4(lo4, h0, m0, l0);
-        ru_split4(hi4, h1, m1, l1);
-        unsigned char* d = sT + buf * (192 * 192) + xst;
-        u32x4 v;
-        v.x = h0.x; v.y = h0.y; v.z = h1.x; v.w = h1.y;
-        *reinterpret_cast<u32x4*>(d) = v;
-        v.x = m0.x; v.y = m0.y; v.z = m1.x; v.w = m1.y;
-        *reinterpret_cast<u32x4*>(d + 64) = v;
-        v.x = l0.x; v.y = l0.y; v.z = l1.x; v.w = l1.y;
-        *reinterpret_cast<u32x4*>(d + 128) = v;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          if (wlo[i] >= 0) *reinterpret_cast<u32x4*>(sR + buf * RU_SLOT + wlo[i]) = wr[i];
-      };
-      auto compute1 = [&](int buf) {
-        const unsigned char* pb = sT + buf * (192 * 192) + (px1 * 32 + l31) * 192;
-        const unsigned char* wb = sR + buf * RU_SLOT + l31 * 192;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 p[3], w[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) p[pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 64 + fsub[ks]);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(wb + c1b * (32 * 192) + pl * 64 + fsub[ks]);
-          RU_MFMA6(acc1[1], w, p);
-          if (two1) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 64 + fsub[ks]);
-            RU_MFMA6(acc1[0], w, p);
-          }
-        }
-      };
-      constexpr int K1 = RU_C / 32;
-      gload1(0, xr0, wr0);
-      sstore1(0, xr0, wr0);
-      gload1(1, xr1, wr1);
-      gload1(2, xr0, wr0);
-      __syncthreads();
-#pragma unroll 1
-      for (int k = 0; k < K1; k += 2) {
-        sstore1(1, xr1, wr1);
-        if (k + 3 < K1) gload1(k + 3, xr1, wr1);
-        compute1(0);
-        __syncthreads();
-        if (k + 2 < K1) sstore1(0, xr0, wr0);
-        if (k + 4 < K1) gload1(k + 4, xr0, wr0);
-        compute1(1);
-        __syncthreads();
-      }
-    }
-    stamp(1);
-    const __amdgpu_buffer_rsrc_t r_pi = desc(pend_x), r_po = desc(pend_out);
-    epi_load(0, xva, r_pi);                        // (in front of the LDS-DMA instructions: the first barrier covers it)
-    const __amdgpu_buffer_rsrc_t r_w2 = desc(P.w2);
-    dma_slab(r_w2, slab2(0), 0);
-    dma_slab(r_w2, slab2(1), 1);
-
-    // ---- t1 conversion of one (pixel tile px1, channel tile ct) accumulator, 8-channel group j
-    const int row1_ = px1 * 32 + l31, lh_ = lh;
-    bool in1;
-    {
-      const int row1 = row1_;
-      const int hy = row1 / RU_HW, hx = row1 - hy * RU_HW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      in1 = (unsigned)iy < (unsigned)u_H && (unsigned)ix < (unsigned)u_W;
-    }
-    auto t1_slice = [&](const f32x16& a, int ct, int j) {
-      int row1 = row1_, lh = lh_;                  // opaque copies: the slice's (tile-invariant) addresses are computed
-      asm volatile("" : "+v"(row1), "+v"(lh));     // here, not in front of the tile loop (they would be spilled)
-      const float4 bb = *reinterpret_cast<const float4*>(sBias + ct * 32 + 8 * j + 4 * lh);
-      float v[4] = {a[4 * j] + bb.x, a[4 * j + 1] + bb.y, a[4 * j + 2] + bb.z, a[4 * j + 3] + bb.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = in1 ? ru_gelu(v[i]) : 0.f;
-      uint2 h, m, l;
-      ru_split4(v, h, m, l);
-      if (row1 < RU_NHALO) {
-        unsigned char* d = sT + row1 * RU_TROW + ct * 192 + ((j ^ ((row1 >> 2) & 3)) << 4) + lh * 8;
-        *reinterpret_cast<uint2*>(d) = h;
-        *reinterpret_cast<uint2*>(d + 64) = m;
-        *reinterpret_cast<uint2*>(d + 128) = l;
-      }
-    };
-    if (two1) {                                    // group 0 now; groups 1 and 2 inside GEMM2
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t1_slice(acc1[0], 0, j);
-    }
-    stamp(2);
-
-    // =============================================================== GEMM2, 27 slabs, unrolled; side jobs in its idle slots
-    f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    // operand fragments of ONE 16-channel k-step (3 planes of the pixel tile, 3 of the weight tile: 24 registers); two
-    // sets, F0 = step 0 and F1 = step 1 of a slab, each refilled while the other one's six MFMAs run
-    auto read2 = [&](int k, int ks, const unsigned char* slot, bf16x8 (&p)[3], bf16x8 (&w)[3]) {
-      const int g = k / 9, tap = k - g * 9;
-      const int ty = tap / 3, tx = tap - ty * 3;
-      // (the 27 slabs' operand addresses are the same for every tile: left alone, hipcc computes them all in front of the
-      // tile loop and keeps them in ~60 spilled registers; an opaque copy of the lane's base row pins the few
-      // instructions of each address to its slab)
-      int hb = hb2;
-      asm volatile("" : "+v"(hb));
-      const int hrow = hb + ty * RU_HW + tx;
-      const int sw = (hrow >> 2) & 3;
-      const unsigned char* pb = sT + hrow * RU_TROW + g * 192 + (((2 * ks + lh) ^ sw) << 4);
-      const unsigned char* wb = slot + (ct2 * 32 + l31) * 192 + fsub[ks];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) p[pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 64);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 64);
-    };
-    bf16x8 p0[3], w0[3], p1[3], w1[3];
-    ru_bar<2>();                                   // slab 0 and group 0 of t1 visible (slab 1 may be in flight)
-    dma_slab(r_w2, slab2(2), 2);
-    read2(0, 0, sR, p0, w0);
-    ru_static_for([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      read2(k, 1, sR + (k % 3) * RU_SLOT, p1, w1);
-      RU_MFMA6(acc2, w0, p0);                      // slab k, step 0
-      if constexpr (k + 1 < 27) {
-        // slab k+1 landed everywhere; every wave has issued its last reads of slab k (and waited for them)
-        if (rank == 0) ru_bar<ru_vmcnt(k, 0)>();
-        else if (rank == 1) ru_bar<ru_vmcnt(k, 1)>();
-        else ru_bar<ru_vmcnt(k, 2)>();
-        if constexpr (k + 3 < 27) dma_slab(r_w2, slab2(k + 3), k % 3);
-      }
-      // ---- side jobs (schedule: ru_side_vmem / ru_t1_slot), placed where only ONE fragment set is live and IN FRONT of
-      // this wave's next MFMAs: a wave issues in order and its MFMAs queue behind its two partners' on the SIMD's matrix
-      // pipe, so behind them the side job would start when the pipe falls idle; here it runs while the partners' execute
-      if constexpr (k < 9) {                       // group 1 of t1 (waves 6..11), read from slab 9 on
-        if constexpr (ru_t1_slot(k, 1, 1) >= 0) { if (!two1 && rank == 1) t1_slice(acc1[1], 1, ru_t1_slot(k, 1, 1)); }
-        if constexpr (ru_t1_slot(k, 1, 2) >= 0) { if (!two1 && rank == 2) t1_slice(acc1[1], 1, ru_t1_slot(k, 1, 2)); }
-      } else if constexpr (k < 18) {               // group 2 (waves 0..5), read from slab 18 on
-        if constexpr (ru_t1_slot(k, 2, 0) >= 0) { if (two1 && rank == 0) t1_slice(acc1[1], 2, ru_t1_slot(k, 2, 0)); }
-        if constexpr (ru_t1_slot(k, 2, 1) >= 0) { if (two1 && rank == 1) t1_slice(acc1[1], 2, ru_t1_slot(k, 2, 1)); }
-      }
-      if constexpr (k < 24) {                      // epilogue slice k/3 of the previous tile on the wave of rank k%3
-        if (rank == k % 3) {
-          epi_slice(k / 3, xva, r_po);
-          if constexpr (k / 3 + 1 < 8) epi_load(k / 3 + 1, xva, r_pi);
-        }
-      }
-      if constexpr (k + 1 < 27) read2(k + 1, 0, sR + ((k + 1) % 3) * RU_SLOT, p0, w0);
-      RU_MFMA6(acc2, w1, p1);                      // slab k, step 1
-    }, std::make_integer_sequence<int, 27>{});
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all reads of t1 and of the ring are done
-    stamp(3);
-    const __amdgpu_buffer_rsrc_t r_w3 = desc(P.w3);
-    dma_slab(r_w3, slab3(0), 0);
-    dma_slab(r_w3, slab3(1), 1);
-
-    // ---- t2 over t1
-    {
-      const int row = px2 * 32 + l31;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bb = *reinterpret_cast<const float4*>(sBias + RU_C2 + ct2 * 32 + 8 * j + 4 * lh);
-        float v[4] = {acc2[4 * j] + bb.x, acc2[4 * j + 1] + bb.y, acc2[4 * j + 2] + bb.z, acc2[4 * j + 3] + bb.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ru_gelu(v[i]);
-        uint2 h, m, l;
-        ru_split4(v, h, m, l);
-        unsigned char* d = sT + row * RU_TROW + ct2 * 192 + ((j ^ rsw) << 4) + lh * 8;
-        *reinterpret_cast<uint2*>(d) = h;
-        *reinterpret_cast<uint2*>(d + 64) = m;
-        *reinterpret_cast<uint2*>(d + 128) = l;
-      }
-    }
-    stamp(4);
-
-    // =============================================================== GEMM3, 6 slabs
-    f32x16 acc3[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc3[q][r] = 0.f;
-    auto mma = [&](f32x16& acc, bf16x8 (&p)[2][3], bf16x8 (&w)[2][3]) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) RU_MFMA6(acc, w[ks], p[ks]);
-    };
-    bf16x8 pA[2][3], wA[2][3], pB[2][3], wB[2][3];
-    auto read3 = [&](int g, const unsigned char* slot, bf16x8 (&p)[2][3], bf16x8 (&w)[2][3]) {
-      const unsigned char* pb = sT + (px2 * 32 + l31) * RU_TROW + g * 192;
-      const unsigned char* wb = slot + (ct2 * 32 + l31) * 192;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) p[ks][pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 64 + fsub[ks]);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[ks][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 64 + fsub[ks]);
-      }
-    };
-    // (the stores of the deferred epilogue were issued before the first of these LDS-DMA instructions: vmcnt(2) covers them)
-    ru_bar<2>();
-    dma_slab(r_w3, slab3(2), 2);
-    read3(0, sR, pA, wA);
-    ru_bar<2>();
-    dma_slab(r_w3, slab3(3), 0);
-    read3(0, sR + RU_SLOT, pB, wB);
-    mma(acc3[0], pA, wA);
-    ru_bar<2>();
-    dma_slab(r_w3, slab3(4), 1);
-    read3(1, sR + 2 * RU_SLOT, pA, wA);
-    mma(acc3[1], pB, wB);
-    ru_bar<2>();
-    dma_slab(r_w3, slab3(5), 2);
-    read3(1, sR, pB, wB);
-    mma(acc3[0], pA, wA);
-    ru_bar<2>();
-    read3(2, sR + RU_SLOT, pA, wA);
-    mma(acc3[1], pB, wB);
-    ru_bar<0>();
-    read3(2, sR + 2 * RU_SLOT, pB, wB);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile end: every wave holds its last fragments; t2, the ring
-    mma(acc3[0], pA, wA);                                             // and (next tile, other problem) the biases may be overwritten
-    mma(acc3[1], pB, wB);
-    stamp(5);
-
-    // ---- this tile's epilogue becomes the pending one: fold b3 in now (the next tile may belong to another problem)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bb = *reinterpret_cast<const float4*>(sBias + 2 * RU_C2 + (q * 3 + ct2) * 32 + 8 * j + 4 * lh);
-        accP[q][4 * j] = acc3[q][4 * j] + bb.x;
-        accP[q][4 * j + 1] = acc3[q][4 * j + 1] + bb.y;
-        accP[q][4 * j + 2] = acc3[q][4 * j + 2] + bb.z;
-        accP[q][4 * j + 3] = acc3[q][4 * j + 3] + bb.w;
-      }
-    {
-      const int r = px2 * 32 + l31;
-      const int iy = y0 + (r >> 4), ix = x0 + (r & 15);
-      const bool ok = iy < u_H && ix < u_W;
-      const unsigned pix = (unsigned)((img * u_H + iy) * u_W + ix);
-      pend_xo = ok ? pix * (unsigned)u_ldx * 4u : 0x80000000u;
-      pend_oo = ok ? pix * (unsigned)u_ldo * 4u : 0x80000000u;
-      pend_x = P.x;
-      pend_out = P.out;
-    }
-    stamp(6);
-  }
-  // ---- the last tile's epilogue
-  if (cur_pi >= 0) {
-    const __amdgpu_buffer_rsrc_t r_pi = desc(pend_x), r_po = desc(pend_out);
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-      epi_load(sl, xva, r_pi);
-      epi_slice(sl, xva, r_po);
-    }
-  }
-}
-
 static long long* g_ru_dbg = nullptr;
-static int g_ru_dma = -1;   // 2 = persistent kernel, LDS-DMA ring, deferred epilogue (default); 1 / 0 = the one-tile-per-workgroup
-                            // kernel with the LDS-DMA ring / register-staged weights (VAMPIC_RU_DMA=1|0: the A/B arms)
+static int g_ru_dma = -1;   // 1 = weight slabs by LDS-DMA through the three-slot ring (default), 0 = register-staged, two LDS
+                            // buffers (VAMPIC_RU_DMA=0: the A/B arm); -1 = not chosen yet
 
 }  // namespace vam
 
@@ -1020,7 +559,7 @@ using namespace vam;
 extern "C" {
 
 int vam_resunit_set_dma(int mode) {
-  g_ru_dma = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
+  g_ru_dma = mode < 0 ? -1 : (mode ? 1 : 0);
   return VAM_OK;
 }
 
@@ -1069,23 +608,13 @@ int vam_resunit_group(const vam_resunit* probs, int nprob, void* stream) {
   for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
   if (g_ru_dma < 0) {
     const char* e = getenv("VAMPIC_RU_DMA");
-    g_ru_dma = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
+    g_ru_dma = (e && e[0] == '0') ? 0 : 1;
   }
   int per_xcd = 0;
   for (int i = 0; i < nprob; ++i) per_xcd += (ga.tile_start[i + 1] - ga.tile_start[i] + 7) / 8;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set[3] = {false, false, false};
+  static bool attr_set[2] = {false, false};
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
-  if (g_ru_dma == 2) {
-    if (!attr_set[2]) {
-      (void)hipFuncSetAttribute((const void*)resunit192p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RU_LDS_P);
-      attr_set[2] = true;
-    }
-    // one workgroup per CU; an XCD's 32 workgroups (blockIdx & 7) walk that XCD's share of every problem's tiles
-    const int wg_per_xcd = per_xcd < 32 ? per_xcd : 32;
-    hipLaunchKernelGGL(resunit192p_kernel, dim3(8 * wg_per_xcd), dim3(RU_NT), RU_LDS_P, s, ga);
-    return check_launch("resunit192p_kernel");
-  }
   if (g_ru_dma) {
     if (!attr_set[1]) {
       (void)hipFuncSetAttribute((const void*)resunit192_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RU_LDS);

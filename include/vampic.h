@@ -187,10 +187,8 @@ typedef struct vam_resunit {
 size_t vam_resunit_struct_size(void);
 int vam_resunit_supported(int C, int H, int W);
 int vam_resunit_group(const vam_resunit* problems, int n_problems, void* stream);
-/* Measurement hook: 2 (default) = persistent kernel (LDS-DMA weight ring, epilogue and two thirds of the first
- * conversion deferred into the 3x3's idle issue slots); 1 / 0 = one tile per workgroup with the LDS-DMA ring /
- * register-staged weights (the A/B arms); -1 = follow the environment variable VAMPIC_RU_DMA.  All three are
- * bit-identical. */
+/* Measurement hook: 1 (default) = weight slabs by LDS-DMA through a three-slot ring, 0 = register-staged (the A/B
+ * arm), -1 = follow the environment variable VAMPIC_RU_DMA.  Both are bit-identical. */
 int vam_resunit_set_dma(int mode);
 /* Measurement hook: device buffer receiving 8 cycle-counter stamps per workgroup at the kernel's phase boundaries
  * (scratch/ru_phases.py); NULL (default) = off. */

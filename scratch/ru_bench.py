@@ -37,7 +37,7 @@ pf, of = build(True)
 flops = K * 2.0 * 32 * 64 * 64 * (192 * 96 * 2 + 96 * 96 * 9)
 res = {}
 for rnd in range(3):
-    for name, plan, dma in (("three launches", p3, 2), ("fused, persistent", pf, 2), ("fused, LDS-DMA ring", pf, 1), ("fused, register-staged", pf, 0)):
+    for name, plan, dma in (("three launches", p3, 1), ("fused, LDS-DMA ring", pf, 1), ("fused, register-staged", pf, 0)):
         lib.vam_resunit_set_dma(dma)
         res.setdefault(name, []).append(timeit(plan))
 lib.vam_resunit_set_dma(-1)

@@ -13,7 +13,7 @@ plan = engine.Plan("cuda")
 engine.lower_residual_units(plan, mods, xs)
 nblk = K * 32 * 8 * 4
 dbg = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
-for dma in (2, 1):
+for dma in (1, 0):
     lib.vam_resunit_set_dma(dma)
     for _ in range(3):
         plan.run()
@@ -23,10 +23,6 @@ for dma in (2, 1):
     d = dbg.view(nblk, 8).cpu().double()
     ph = d[:, 1:7] - d[:, 0:6]
     names = ["GEMM1 (x + W1 staged)", "t1 write", "GEMM2 (27 items)", "t2 write", "GEMM3 (6 items)", "epilogue (issue)"]
-    if dma == 2:
-        names = ["tile setup + GEMM1", "t1 group 0", "GEMM2 + deferred work", "t2 write", "GEMM3", "fold bias"]
-        d = d[(d[:, 6] > 0)]        # workgroups that ran a second tile (stamps are taken on it)
-        ph = d[:, 1:7] - d[:, 0:6]
     tot = (d[:, 6] - d[:, 0])
     print(f"dma={dma}: s_memtime ticks (100 MHz reference clock ticks if constant-rate) per workgroup, median over {nblk}: total {tot.median():.0f}")
     for n, col in zip(names, ph.t()):

@@ -235,9 +235,8 @@ def test_conv_result_is_independent_of_tiling():
 def test_fused_residual_unit_is_bit_identical(hw, batch, monkeypatch):
     """csrc/resunit.hip runs a ResidualUnit (layers/layers.py:30-48) as ONE launch with both C/2-channel intermediates
     in LDS.  Same split-operand arithmetic in the same canonical K order as three conv launches: the results must agree
-    bit for bit (image sizes that are not multiples of the 8 x 16 tile included) in all three variants of the kernel — the
-    persistent one with the deferred epilogue, and the one-tile-per-workgroup arms with the weight slabs staged by
-    LDS-DMA and by registers; and they agree with ATen's fp32 unit."""
+    bit for bit (image sizes that are not multiples of the 8 x 16 tile included), with the weight slabs staged by LDS-DMA
+    and by registers alike; and they agree with ATen's fp32 unit."""
     lib = L.load()
     m = Ly.ResidualUnit(192)
     sd = _fill(m, 31)
@@ -247,7 +246,7 @@ def test_fused_residual_unit_is_bit_identical(hw, batch, monkeypatch):
     assert ops.resunit_supported(ops.from_nchw(xc)), "C = 192 has a fused kernel"
     outs = {}
     with torch.no_grad():
-        for mode in (2, 1, 0):        # persistent kernel (default) / one tile per workgroup with the LDS-DMA ring / register-staged
+        for mode in (1, 0):           # weight slabs by LDS-DMA (default) / register-staged
             lib.vam_resunit_set_dma(mode)
             try:
                 outs[f"fused mode={mode}"] = m(xc).clone()
