@@ -249,7 +249,7 @@ def main():
         # bf16x3 mode: every algorithmic (fp32-equivalent) FLOP costs 6 bf16 MFMA FLOPs, so the ceiling of this
         # algorithm on the bf16 pipe is 2500 / 6 = 416.7 TF/s; `achieved` stays ALGORITHMIC FLOP / time
         peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one step)",
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel + resunit192_kernel (all convolution launches of one step; a fused residual unit is one launch of three convolutions)",
                 "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 partial products on v_mfma_f32_32x32x16_bf16, "
                                "fp32 accumulate") if split else "fp32 operands on v_mfma_f32_32x32x2_f32",
                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -30,13 +30,15 @@ def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
-    fam = {"conv_igemm": "conv_igemm_kernel", "win_attn": "win_attn_kernel", "variance_mask": "variance_mask_kernel",
-           "gauss_tail": "gauss_tail_kernel"}
+    # the convolution family = the implicit-GEMM kernel and the fused residual-unit kernel (three convolutions per launch)
+    fam = {"conv_igemm": ("conv_igemm_kernel", "resunit192_kernel"), "win_attn": ("win_attn_kernel",),
+           "variance_mask": ("variance_mask_kernel",), "gauss_tail": ("gauss_tail_kernel",)}
     res = {}
-    for name, pat in fam.items():
-        fk = sum(v[0] for k, v in f.items() if pat in k)
-        wk = sum(v[0] for k, v in w.items() if pat in k)
-        n = sum(v[1] for k, v in f.items() if pat in k)
+    for name, pats in fam.items():
+        hit = lambda k: any(p_ in k for p_ in pats)
+        fk = sum(v[0] for k, v in f.items() if hit(k))
+        wk = sum(v[0] for k, v in w.items() if hit(k))
+        n = sum(v[1] for k, v in f.items() if hit(k))
         res[name] = {"launches_per_step": n // passes,
                      "fetch_bytes_per_step": 2 * fk * 1024 / passes,      # x2: gfx950 FETCH_SIZE correction
                      "write_bytes_per_step": wk * 1024 / passes,
