@@ -74,7 +74,7 @@ struct GroupArgs {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
-    case VAM_ACT_GELU: return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));
+    case VAM_ACT_GELU: return vam_gelu(v);
     case VAM_ACT_LEAKY: return v > 0.f ? v : v * 0.01f;
     case VAM_ACT_HALF_TANH: return 0.5f * tanhf(v);
     case VAM_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));

@@ -64,7 +64,7 @@ struct RuArgs {
   RuP p[VAM_MAX_GROUP];
 };
 
-__device__ __forceinline__ float ru_gelu(float v) { return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ru_gelu(float v) { return vam_gelu(v); }
 
 // exact 3-way split by truncation of four fp32 values into packed bf16 pairs (conv_igemm.hip, same formula)
 __device__ __forceinline__ void ru_split4(const float (&v)[4], uint2& h, uint2& m, uint2& l) {

@@ -20,7 +20,7 @@ struct EwArgs {
   int flag;
 };
 
-__device__ __forceinline__ float gelu_f(float v) { return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float v) { return vam_gelu(v); }
 // d/dv [ v * Phi(v) ] = Phi(v) + v * phi(v)
 __device__ __forceinline__ float gelu_d(float v) {
   return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);

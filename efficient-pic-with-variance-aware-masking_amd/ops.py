@@ -639,13 +639,22 @@ _GRAVEYARD: list = []               # (exec handle, torch stream it was last lau
 class Graph:
     """hipGraph capture of a sequence of libvampic launches on the current stream.
 
-    Lifetime: an executable graph must outlive its last replay, and it must not be destroyed while the host thread is
-    capturing (the round-2 crash: ``net.update()`` dropped plans whose graphs had replays in flight on their private
-    streams; their destructors ran whenever the cyclic garbage collector got to them — possibly inside the next plan's
-    capture — and the following ``hipGraphLaunch`` faulted).  So nothing is destroyed from ``__del__``: a dropped graph
-    (``close()`` or garbage collection) only parks its handle, and :func:`drain_graveyard` — called by the plans at
-    their entry points, never during a capture — synchronises the stream each handle was last launched on and then
-    destroys it, checking the return code."""
+    Lifetime.  A dropped graph (``close()`` or garbage collection) only parks its handle: no HIP call from ``__del__``,
+    which can run inside another plan's capture.  :func:`drain_graveyard` — called by the plans at their entry points,
+    never during a capture — synchronises the stream each parked handle was last launched on and then RETIRES it: the
+    handle is kept for the life of the process and ``hipGraphExecDestroy`` is not called.
+
+    Why not destroyed (round 3, demonstrated; ROCm 7.2 / gfx950).  The host segfault of round 2 (``hipGraphLaunch``
+    inside tests/test_gpu_bitstream.py, right after ``net.update()`` had dropped the model's plans) came back
+    DETERMINISTICALLY with the deferred, synchronised, return-code-checked destruction of round 3 in place, in the test
+    order ops -> model -> golden -> config_variants -> bitstream (two runs of two; ~20 executable graphs destroyed at
+    that entry point, then the capture and launch of a new plan faults inside the runtime, gpurun_out/r3_segv.log).  The
+    same order with the handles retired instead of destroyed: 73 passed (gpurun_out/r3_segv2.log).  Every destroyed
+    graph had finished (its stream synchronised), none was destroyed twice (``close`` clears the handle), no capture was
+    active: the library's side of the contract holds, and the only difference between crash and no crash is the call
+    to hipGraphExecDestroy.  A retired executable graph costs host memory for its kernel arguments (~0.3 MB for a
+    230-launch plan); plans are dropped by ``update`` / ``load_state_dict`` / ``_apply``, i.e. a handful of times per
+    process.  ``VAMPIC_GRAPH_DESTROY=1`` restores the destruction (for a runtime where it is safe)."""
 
     def __init__(self):
         self.exec = C.c_void_p(None)
@@ -683,7 +692,8 @@ class Graph:
 
 
 def drain_graveyard():
-    """Destroy the executable graphs dropped since the last call.  No-op while a capture is in progress."""
+    """Retire (or, with VAMPIC_GRAPH_DESTROY=1, destroy) the executable graphs dropped since the last call, after
+    synchronising the streams they last ran on.  No-op while a capture is in progress."""
     if _CAPTURING or not _GRAVEYARD:
         return
     dead = list(_GRAVEYARD)
@@ -694,12 +704,22 @@ def drain_graveyard():
             seen.add(st.cuda_stream)
             st.synchronize()            # the last replay of every dropped graph has finished
     lib = L.load()
+    if os.environ.get("VAMPIC_GRAPH_DESTROY", "0") != "1":   # default: see the class docstring
+        _RETIRED.extend(h for h, _ in dead)
+        return
     for handle, _ in dead:
         L.check(lib.vam_graph_destroy(C.c_void_p(handle)), "vam_graph_destroy")
 
 
+_RETIRED: list = []      # handles of dropped executable graphs, kept alive on purpose
+
+
 def graveyard_size() -> int:
     return len(_GRAVEYARD)
+
+
+def retired_graphs() -> int:
+    return len(_RETIRED)
 
 
 _PROF_ON = False

@@ -12,7 +12,7 @@ import vampic                      # noqa: E402
 import vampic.synth as synth       # noqa: E402
 from vampic import layers as Ly    # noqa: E402
 
-from conftest import check_bpp_abs, min_clean_cases      # noqa: E402
+from conftest import check_bpp_abs, min_clean_cases, max_boundary_events      # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 Q_LEVS = [0, 0.01, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.5, 2, 2.5, 3, 5, 7.7, 9.99, 10, 12]
@@ -58,6 +58,7 @@ def _check_against_vectors(tag, x, o, gold, scal, n_pix, net=None, sd=None, q=No
         ref = O.forward_single_quality(sd, x, q)
         aud = audit(gpu_latent(net, *shape, q == 0), {k: v.cpu() for k, v in o.items() if torch.is_tensor(v)}, ref, q)
         assert aud["violations"] == [], (tag, aud)
+        assert aud["explained"] <= max_boundary_events(o["y_hat"].numel()), (tag, aud)
         if flips == 0 and (aud["sym_flips"] or aud["mask_flips"]):
             flips = aud["sym_flips"] + aud["mask_flips"]          # a flip the LRP happened to hide in y_hat
     if flips == 0:
@@ -121,6 +122,7 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         cpu = {k: v.cpu() for k, v in o.items() if torch.is_tensor(v)}
         aud = audit(gpu_latent(net, 1, 256, 256, q == 0), cpu, ref, q)
         assert aud["violations"] == [], (tag, aud)
+        assert aud["explained"] <= max_boundary_events(cpu["y_hat"].numel()), (tag, aud)
         total += 1
         ys, xs = cpu["y_hat"][:, ::4, ::2, ::2].numpy(), cpu["x_hat"][:, :, ::8, ::8].numpy()
         if aud["sym_flips"] or aud["mask_flips"]:

@@ -38,11 +38,11 @@ def _cmp(out, ref, B, H, W, q):
 #   * in a case WITH differences, every difference in a slice whose inputs still agree must be a PROVEN boundary event
 #     in the oracle's own numbers (residual within 1e-3 of x.5 / sigma within 2e-4 of the threshold); only slices
 #     downstream of such an event may differ freely, and then by bounded counts;
-#   * at least 90 % of the cases must be difference-free (a real bug flips far more than the fp32-noise rate).
+#   * proven boundary events are few per case (conftest.max_boundary_events) and at least 75 % of the cases have none at
+#     all (conftest.min_clean_cases: why not 90 %).
 SHAPES = [(1, 64, 64), (1, 64, 128), (1, 128, 128)]
 QS = [0, 0.5, 2.5, 10]
-# (the gate itself: conftest.min_clean_cases — 90 % in whole cases)
-from conftest import check_bpp_abs, min_clean_cases, BPP_ABS_TARGET     # noqa: E402  (absolute rate bound of the double route)
+from conftest import check_bpp_abs, min_clean_cases, max_boundary_events, BPP_ABS_TARGET     # noqa: E402  (absolute rate bound of the double route)
 _BPP_ABS = []
 _BPP_RATE = []
 
@@ -60,6 +60,7 @@ def _one_case(net, sd, shape, seed, q):
     psnr_g, psnr_r = O.psnr(x, out["x_hat"].cpu()), O.psnr(x, ref["x_hat"])
     n = out["y_hat"].numel()
     assert aud["violations"] == [], (shape, seed, q, aud)        # every first difference is a proven boundary event
+    assert aud["explained"] <= max_boundary_events(n), (shape, seed, q, aud)     # ... and there are only a handful of them
     if aud["sym_flips"] == 0 and aud["mask_flips"] == 0:
         assert rep["latent_symbol_flips"] == 0 and rep.get("mask_flips", 0) == 0, (shape, seed, q, rep)
         assert abs(psnr_g - psnr_r) <= 1e-4, (shape, seed, q, psnr_g, psnr_r)          # dB

@@ -1,4 +1,5 @@
-"""Plan / hipGraph lifetime (round-2 host segfault): dropping plans between replays."""
+"""Plan / hipGraph lifetime (round-2 host segfault): dropping plans between replays.  Round 3 found
+the crash again, deterministically, behind hipGraphExecDestroy itself (ops.Graph docstring): dropped graphs are retired."""
 import copy
 import gc
 
@@ -14,7 +15,7 @@ from vampic import ops           # noqa: E402
 def test_dropping_plans_between_graph_replays(gpu_model):
     """The sequence of the crash record (gpurun_out/full_gpu_r02d.log: `codec` fixture -> net.update() -> _plans.clear()
     with replays of the dropped plans' graphs possibly still running, then capture + launch of a new plan): dropped
-    executable graphs are only PARKED (no HIP call from a destructor / during a capture) and destroyed at the next plan
+    executable graphs are only PARKED (no HIP call from a destructor / during a capture) and retired at the next plan
     entry point after their stream has been synchronised.  Runs once — no loops."""
     net = copy.deepcopy(gpu_model[0])
     x = synth.synth_image(2, 64, 128, seed=5).cuda()
@@ -40,3 +41,26 @@ def test_dropping_plans_between_graph_replays(gpu_model):
     torch.cuda.synchronize()
     ops.drain_graveyard()
     assert ops.graveyard_size() == 0
+
+
+def test_many_dropped_graphs_then_a_new_plan(gpu_model):
+    """The shape of the round-3 crash: a model that has replayed plans of several shapes and qualities (about twenty
+    executable graphs) drops them all in ``update()``; the next call builds, captures and replays a new plan.  With
+    hipGraphExecDestroy in ``drain_graveyard`` this sequence faulted inside hipGraphLaunch at the end of the order
+    ops -> model -> golden -> config_variants -> bitstream; with the handles retired it must simply work."""
+    net = copy.deepcopy(gpu_model[0])
+    xs = [synth.synth_image(1, 64, 64, seed=1).cuda(), synth.synth_image(1, 64, 128, seed=2).cuda(),
+          synth.synth_image(2, 64, 64, seed=3).cuda()]
+    before = ops.retired_graphs()
+    with torch.no_grad():
+        ref = net.forward_single_quality(xs[1], 2.5)
+        for x in xs:
+            for q in (0, 0.25, 0.5, 1, 2.5, 5, 10):
+                net.forward_single_quality(x, q)
+        net.update()
+        assert ops.graveyard_size() >= 15
+        again = net.forward_single_quality(xs[1], 2.5)
+        assert ops.graveyard_size() == 0 and ops.retired_graphs() >= before + 15
+        enc = net.compress(xs[1], quality=2.5)
+        dec = net.decompress(enc["strings"], enc["shape"], quality=2.5)
+    assert torch.equal(ref["x_hat"], again["x_hat"]) and torch.equal(dec["x_hat"], again["x_hat"])
