@@ -260,8 +260,8 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
     };
     constexpr int K1 = RU_C / 32;   // 6 items
     gload1(0, xr0, wr0);
+    gload1(1, xr1, wr1);                             // (in flight while chunk 0 is split and stored)
     sstore1(0, xr0, wr0);
-    gload1(1, xr1, wr1);
     gload1(2, xr0, wr0);
     __syncthreads();
 #pragma unroll 1
