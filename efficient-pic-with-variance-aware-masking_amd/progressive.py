@@ -6,6 +6,11 @@ Same container and call surface as the reference harness (src/test/functions_enc
 functions_decode.py:9-229, test/utils.py:16-54) so that ``demo.py`` can import these two functions
 instead:  ``bitstreams = {"q_list", "shape", "z", "base", "progressive"}``.  Everything numeric goes
 through the model's module-level surface (HIP kernels); this file is orchestration only.
+
+Model variants: like the reference's harness this one follows ``multiple_encoder`` (functions_encode.py:78-83),
+``multiple_decoder`` (functions_decode.py:107,224), ``multiple_hyperprior`` (test/utils.py:20-31) and any
+``support_progressive_slices``; and like it, it is defined for ``delta_encode=True`` (functions_encode.py:113-114
+names the residual only there) and ``all_scalable=True`` (the parameter chain of test/utils.py:35-54 never sees a mask).
 """
 from __future__ import annotations
 
@@ -61,16 +66,27 @@ def _chain(model, y_hat_base, mu_base, std_base, means_h, scales_h, rems, y_chec
     return yb, mus, scales, supports
 
 
+def _check_variant(model):
+    if not (model.delta_encode and getattr(model, "all_scalable", True)):
+        raise NotImplementedError("the progressive container is defined for delta_encode=True and all_scalable=True "
+                                  "(reference src/test/functions_encode.py:113-114, test/utils.py:35-54)")
+
+
+def _synthesis(model, i):
+    return model.g_s[i] if model.multiple_decoder else model.g_s
+
+
 def encode(model, x_padded, save_path=None, rems=False, q_list: Sequence[float] = Q_LIST, y_checkpoints=None):
     """functions_encode.py:15-66.  Returns (bitstreams, [bits_z, bits_base, bits_per_layer])."""
     assert x_padded.shape[0] == 1, "the progressive container is per image (ProgMask squeezes batch 1)"
+    _check_variant(model)
     with torch.no_grad():
         base = model.compress(x_padded, quality=0)
         bit = {"q_list": list(q_list), "shape": base["shape"], "z": base["strings"][1], "base": base["strings"][0]}
         bits_z = 8.0 * sum(len(s) for s in bit["z"])
         bits_base = 8.0 * sum(len(s[0]) for s in bit["base"])
         # residual latents and their parameters (functions_encode.py:79-160)
-        y = torch.cat([model.g_a[0](x_padded), model.g_a[1](x_padded)], dim=1)
+        y = torch.cat([model.g_a[0](x_padded), model.g_a[1](x_padded)], dim=1) if model.multiple_encoder else model.g_a(x_padded)
         means_h, scales_h, _ = model.compute_hyperprior(y)
         yb, mus, scales, _ = _chain(model, base["y_hat_base"], base["mean_base"], base["scale_base"], means_h, scales_h,
                                     rems, y_checkpoints)
@@ -96,9 +112,11 @@ def encode(model, x_padded, save_path=None, rems=False, q_list: Sequence[float] 
 def _decode_hyper(model, z_strings, shape, q_ind):
     """test/utils.py:16-33."""
     z_hat = model.entropy_bottleneck.decompress(z_strings, shape)
+    if not model.multiple_hyperprior:          # one hyper-synthesis pair delivers the parameters of both halves
+        return z_hat, model.h_mean_s(z_hat), model.h_scale_s(z_hat), [z_hat.shape[2] * 4, z_hat.shape[3] * 4]
     means = [model.h_mean_s[0](z_hat)]
     scales = [model.h_scale_s[0](z_hat)]
-    if model.multiple_hyperprior and q_ind != 0:
+    if q_ind != 0:
         means.append(model.h_mean_s[1](z_hat))
         scales.append(model.h_scale_s[1](z_hat))
     return z_hat, torch.cat(means, 1), torch.cat(scales, 1), [z_hat.shape[2] * 4, z_hat.shape[3] * 4]
@@ -129,6 +147,7 @@ def decode(model, bitstreams, q_ind=0, res_base=None, index_hat_slice=None, mean
     that moving to the next quality only decodes the new layer's parameters once."""
     q_list, shape = bitstreams["q_list"], bitstreams["shape"]
     assert q_ind <= len(q_list)
+    _check_variant(model)
     with torch.no_grad():
         if z_data is None:
             z_data = list(_decode_hyper(model, bitstreams["z"], shape, q_ind))
@@ -137,10 +156,10 @@ def decode(model, bitstreams, q_ind=0, res_base=None, index_hat_slice=None, mean
             res_base = _decode_base(model, bitstreams["base"], means_h, scales_h)
         y_hat_base = res_base["y_hat"]
         if q_ind == 0:
-            x_hat = model.g_s[0](y_hat_base).clamp_(0, 1)
+            x_hat = _synthesis(model, 0)(y_hat_base).clamp_(0, 1)
             return {"x_hat": x_hat, "y_hat": y_hat_base, "mu": res_base["mu"], "scale": res_base["scale"],
                     "z_data": z_data, "res_base": res_base}
-        if means_h.shape[1] == model.division_dimension[0]:                # z_data came from a q_ind == 0 call
+        if model.multiple_hyperprior and means_h.shape[1] == model.division_dimension[0]:     # z_data came from a q_ind == 0 call
             z_data = list(_decode_hyper(model, bitstreams["z"], shape, q_ind))
             z_hat, means_h, scales_h, y_shape = z_data
         gc = model.gaussian_conditional
@@ -164,6 +183,6 @@ def decode(model, bitstreams, q_ind=0, res_base=None, index_hat_slice=None, mean
             r = r_hat[j] + 0.5 * torch.tanh(model.lrp_transforms_prog[j](torch.cat([supports[j], r_hat[j]], dim=1)))
             y_prog.append(model.merge(r, yb[j]))
         y_prog = torch.cat(y_prog, 1)
-        x_hat = model.g_s[1](y_prog)
+        x_hat = _synthesis(model, 1)(y_prog)
     return {"x_hat": x_hat, "z_data": z_data, "entropy_data": entropy_data, "y_hat_base": y_hat_base, "y_prog": y_prog,
             "res_base": res_base}

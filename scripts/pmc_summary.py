@@ -49,7 +49,7 @@ def main():
         g.write(open(stats).read())
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(os.path.join(out_dir, f"{tag}_summary.md"), "w") as g:
-        g.write(f"# rocprofv3 summary {tag}\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`\n\n")
+        g.write(f"# rocprofv3 summary {tag}\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16`\n\n")
         g.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows[:20]:
             g.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.1f} |\n")

@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out" "$root/gpurun_out/profiles"
-B="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16"      # (the secondary bf16 leg of the default run would mix its steps into the trace)
 
 echo "[2] kernel trace + stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o tr -- python3 $B > "$out/trace.log" 2>&1
@@ -24,8 +24,8 @@ cp "$st" "$root/profiles/${tag}_kernel_stats.csv"
 echo "[3] timeline"; python3 scripts/trace_overlap.py "$tag" "$tr" > "$out/timeline.log"
 
 echo "[4] traffic counters"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > "$out/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > "$out/write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-graph > "$out/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-graph > "$out/write.log" 2>&1
 fc=$(find "$out/fetch" -name 'f_counter_collection.csv' | head -1); wc=$(find "$out/write" -name 'w_counter_collection.csv' | head -1)
 # bench.py --no-graph runs warmup + steps + 3 (plan build, first eager run, HIP-event pass) forward passes: count them from the trace
 passes=$(grep -c s2d_input_kernel "$(find "$out/fetch" -name 'f_kernel_trace.csv' | head -1)")
@@ -35,12 +35,12 @@ python3 scripts/pmc_summary.py "$tag" "$st" "$fc" "$wc" "$passes" > "$out/pmc_su
 
 echo "[5] MFMA utilisation counters"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  --kernel-trace --output-format csv -d "$out/sq" -o s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > "$out/sq.log" 2>&1
+  --kernel-trace --output-format csv -d "$out/sq" -o s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-graph > "$out/sq.log" 2>&1
 python3 scripts/pmc_mfma.py "$(find "$out/sq" -name 's_counter_collection.csv' | head -1)" "$(find "$out/sq" -name 's_kernel_trace.csv' | head -1)" > "$root/profiles/${tag}_mfma_util.md"
 
 echo "[6] bench (after the counter passes: its traffic field reads profiles/${tag}_pmc_traffic.json)"
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; tail -1 "$out/bench.json" > "$root/profiles/${tag}_bench.json"
-python3 bench.py --dtype bf16 --no-cpu-baseline > "$out/bench_bf16.json" 2>> "$out/bench.err"; tail -1 "$out/bench_bf16.json" > "$root/profiles/${tag}_bench_bf16.json"
+python3 bench.py --dtype bf16 --no-cpu-baseline --no-bf16 > "$out/bench_bf16.json" 2>> "$out/bench.err"; tail -1 "$out/bench_bf16.json" > "$root/profiles/${tag}_bench_bf16.json"
 cp "$root"/profiles/${tag}_* "$root/gpurun_out/profiles/"
 rm -rf "$out/trace" "$out/fetch" "$out/write" "$out/sq"          # raw traces stay on the box (tens of MB)
 echo "[done]"; cat "$root/profiles/${tag}_bench.json"

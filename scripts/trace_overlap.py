@@ -53,7 +53,7 @@ def main():
     serial = [o for o in out if o["kind"] == "serialised"][-3:]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", f"{tag}_timeline.md"), "w") as g:
-        g.write(f"# step timeline {tag}\n\n`rocprofv3 --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`, "
+        g.write(f"# step timeline {tag}\n\n`rocprofv3 --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16`, "
                 f"from the kernel trace (`scripts/trace_overlap.py`; {len(out)} steps in the trace, {per_step} launches each).  "
                 "Two-branch runs (hipGraph replays; two streams with --no-graph) = what `value` / `ms_per_step` time; serialised passes = what the HIP-event figures of `roofline` time.\n\n"
                 "| step kind | launches | wall ms (first start -> last end) | sum of kernel durations ms | of which conv_igemm | union of busy intervals ms | overlapped ms (sum - union) | busy ms per HW queue |\n|---|---|---|---|---|---|---|---|\n")

@@ -88,3 +88,44 @@ def test_config_variant_matches_reference(name):
             enc = net.compress(x.cuda(), quality=q, **kwq)
             dec = net.decompress(enc["strings"], enc["shape"], quality=q, **kwq)
             assert torch.equal(dec["x_hat"], fw["x_hat"]), (name, q)
+
+
+def _variant_model(name):
+    net = vampic.get_model(variant_args(name), "cpu").eval()
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    torch.nn.Module.load_state_dict(net, sd)
+    net = net.cuda()
+    net.update()
+    return net, sd
+
+
+@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single", "sp0", "sp2", "sp8"])
+def test_progressive_container_of_the_variants(name):
+    """The demo's single-bitstream harness (reference src/test/functions_encode.py:15-198, functions_decode.py:58-229) on the
+    constructor variants it is defined for: decoding the first k layers must reconstruct what forward_single_quality(q_k)
+    reconstructs.  (delta_encode=False / all_scalable=False are outside the reference harness too: NotImplementedError.)"""
+    from vampic import progressive as P
+    net, sd = _variant_model(name)
+    x = vampic.synth.synth_image(1, 64, 64, seed=9).cuda()
+    q_list = [0.5, 2.5, 10]
+    bit, (bz, bb, bl) = P.encode(net, x, q_list=q_list)
+    assert len(bit["progressive"]) == len(q_list) and bz > 0 and bb > 0 and all(b > 0 for b in bl)
+    with torch.no_grad():
+        d0 = P.decode(net, bit, q_ind=0)
+        fw0 = net.forward_single_quality(x, 0)
+        assert (d0["x_hat"] - fw0["x_hat"]).abs().max().item() <= 1e-5, name
+        state = {}
+        for k in range(1, len(q_list) + 1):
+            dk = P.decode(net, bit, q_ind=k, z_data=state.get("z"), res_base=d0["res_base"], entropy_data=state.get("e"))
+            state = {"z": dk["z_data"], "e": dk["entropy_data"]}
+            fw = net.forward_single_quality(x, q_list[k - 1])
+            assert (dk["y_prog"] - fw["y_hat"]).abs().max().item() <= 1e-4, (name, k)
+            assert (dk["x_hat"].clamp(0, 1) - fw["x_hat"]).abs().max().item() <= 1e-5, (name, k)
+
+
+def test_progressive_container_rejects_what_the_reference_harness_cannot_do():
+    from vampic import progressive as P
+    for name in ("no_delta_no_mu_rep", "not_all_scalable"):
+        net, sd = _variant_model(name)
+        with pytest.raises(NotImplementedError):
+            P.encode(net, vampic.synth.synth_image(1, 64, 64, seed=9).cuda(), q_list=[0.5])
