@@ -12,6 +12,7 @@
 // Tokens per window <= 64 and head_dim <= 40, so this is VALU work (0.5 % of the FLOPs),
 // not an MFMA shape.
 #include "common.h"
+#include <cstdlib>
 
 namespace vam {
 
@@ -121,6 +122,152 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const float* __restrict__ 
     *reinterpret_cast<float4*>(dst + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 8 x 8 windows on the matrix pipe (round 3).  The kernel above keeps K and V of a (window, head) in LDS and every lane
+// reads every row as a wave-broadcast ds_read_b128: 1,536 of them per wave pace it (222 us per launch at 32x64x64x192,
+// 0 % MFMA).  Here one wave still owns one (window, head), but both products run on v_mfma_f32_32x32x2_f32 — fp32
+// operands, an exact fma chain, so no bf16 split and the same arithmetic as the FMA loops:
+//   S^T = K (Q scale)^T   as 2 x 2 blocks of 32 keys x 32 queries, 12 k-steps of two head-dim elements: the A / B operand
+//         of lane (r, h) in step t is K[key r][2t + h] / Q[query r][2t + h] — registers loaded straight from q / k;
+//   the block's accumulator holds, per lane, ONE query (its column) and 16 keys (rows (e&3) + 8(e>>2) + 4h): bias, shift
+//         mask and the softmax run in the lane's own registers plus one exchange with lane ^ 32;
+//   O^T = V^T P^T   sums over keys = the ROW index of the S^T accumulators, so P^T is the B operand of step e as it stands
+//         (register e of the block, no conversion, no lane movement); the A operand is V[key of (e, h)][d = r], read from
+//         a 6 KB LDS image of V (bank-conflict free: 24-float rows);
+//   the O^T accumulator holds one query and head-dim elements in runs of four: 16-byte stores.
+// 112 MFMAs of 64 cycles per (window, head): 55 us of matrix time per launch at 32x64x64x192.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(64) void win_attn8_mfma_kernel(const float* __restrict__ qkv, int ld_qkv, float* __restrict__ out,
+                                                           int ld_out, const float* __restrict__ table, int B, int H, int W,
+                                                           int C, int heads, int shift, float scale) {
+  static_assert(HD % 4 == 0 && HD <= 32, "head dim: a multiple of 4, one 32-row block of O^T");
+  constexpr int WS = 8, N = 64, KS = HD / 2;
+  constexpr int NT = (2 * WS - 1) * (2 * WS - 1);           // relative-position table entries of one head
+  __shared__ __attribute__((aligned(16))) float sV[N * HD];
+  __shared__ float sTab[NT];
+
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int head = bid % heads;
+  bid /= heads;
+  const int nWx = W / WS, nWy = H / WS;
+  const int wx = bid % nWx;
+  bid /= nWx;
+  const int wy = bid % nWy;
+  const int b = bid / nWy;
+
+  for (int i = lane; i < NT; i += 64) sTab[i] = table[i * heads + head];
+
+  // tokens 32 i + r31 (i = 0, 1): original pixel of window token (ti, tj) under the cyclic shift
+  size_t pix[2];
+  int ti[2], tj[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int tok = 32 * i + r31;
+    ti[i] = tok >> 3;
+    tj[i] = tok & 7;
+    int oy = wy * WS + ti[i] + shift, ox = wx * WS + tj[i] + shift;
+    if (oy >= H) oy -= H;
+    if (ox >= W) ox -= W;
+    pix[i] = ((size_t)b * H + oy) * W + ox;
+  }
+  // operands of S^T: element 2t + h of this lane's two tokens (q pre-scaled), and this half's share of V -> LDS
+  float qa[2][KS], ka[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float* base = qkv + pix[i] * ld_qkv + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 qv = *reinterpret_cast<const float4*>(base + d);
+      const float4 kv = *reinterpret_cast<const float4*>(base + C + d);
+      qa[i][d / 2] = (h ? qv.y : qv.x) * scale;
+      qa[i][d / 2 + 1] = (h ? qv.w : qv.z) * scale;
+      ka[i][d / 2] = h ? kv.y : kv.x;
+      ka[i][d / 2 + 1] = h ? kv.w : kv.z;
+    }
+    // V row of token 32 i + r31: half h copies the float4s d/4 = h, h + 2, ...
+#pragma unroll
+    for (int d = 4 * h; d < HD; d += 8)
+      *reinterpret_cast<float4*>(sV + (32 * i + r31) * HD + d) = *reinterpret_cast<const float4*>(base + 2 * C + d);
+  }
+  f32x16 acc[2][2];          // [key block][query block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[i][t], qa[j][t], acc[i][j], 0, 0, 0);
+  __syncthreads();           // sV, sTab complete
+
+  // ---- bias, shift mask (win_attention.py:163-173), softmax over the keys of each query
+  auto rid1 = [&](int sgrid, int n) { return shift > 0 ? (sgrid < n - WS ? 0 : (sgrid < n - shift ? 1 : 2)) : 0; };
+  float inv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int my_rid = rid1(wy * WS + ti[j], H) * 3 + rid1(wx * WS + tj[j], W);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ui = 4 * i + (e >> 2), uj = 4 * h + (e & 3);       // key = 32 i + 8 (e >> 2) + 4 h + (e & 3) = 8 ui + uj
+        float v = acc[i][j][e] + sTab[(ti[j] - ui + WS - 1) * (2 * WS - 1) + (tj[j] - uj + WS - 1)];
+        const int urid = rid1(wy * WS + ui, H) * 3 + rid1(wx * WS + uj, W);
+        v = v + (urid != my_rid ? -100.0f : 0.0f);
+        acc[i][j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f((acc[i][j][e] - mx) * 1.4426950408889634f);
+        acc[i][j][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32);
+    inv[j] = 1.0f / sum;
+  }
+  // ---- O^T = V^T P^T: k-step (i, e) pairs key 32 i + 8 (e >> 2) + 4 h + (e & 3) of half h with register e of P^T
+  f32x16 o[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+      const float vt = r31 < HD ? sV[key * HD + r31] : 0.f;          // V^T[d = r31][key]
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt, acc[i][j][e], o[j], 0, 0, 0);
+    }
+  // ---- store: lane = query 32 j + r31, registers 4g .. 4g+3 = head-dim elements 8 g + 4 h + 0..3
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float* dst = out + pix[j] * ld_out + head * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 8 * g + 4 * h;
+      if (d < HD)
+        *reinterpret_cast<float4*>(dst + d) = make_float4(o[j][4 * g] * inv[j], o[j][4 * g + 1] * inv[j], o[j][4 * g + 2] * inv[j],
+                                                          o[j][4 * g + 3] * inv[j]);
+    }
+  }
+}
+
 }  // namespace vam
 
 using namespace vam;
@@ -142,6 +289,18 @@ extern "C" int vam_win_attention(const float* qkv, int ld_qkv, float* out, int l
   hipStream_t s = (hipStream_t)stream;
   double tokens = (double)B * H * W;
   ProfScope ps(VAM_FAM_ATTN, s, 4.0 * tokens * ws * ws * C, 4.0 * tokens * 4 * C);
+  static int mfma_env = -1;               // VAMPIC_ATTN_MFMA=0: the FMA kernel for 8 x 8 windows too (A/B measurements)
+  if (mfma_env < 0) {
+    const char* e = getenv("VAMPIC_ATTN_MFMA");
+    mfma_env = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (ws == 8 && hd == 24 && mfma_env) {
+    // one wave per (window, head): fp32 products on the matrix pipe (win_attn8_mfma_kernel)
+    const long nb = (long)B * (H / ws) * (W / ws) * heads;
+    VAM_REQUIRE(nb < (1L << 31), "vam_win_attention: grid too large");
+    hipLaunchKernelGGL((win_attn8_mfma_kernel<24>), dim3((unsigned)nb), dim3(64), 0, s, qkv, ld_qkv, out, ld_out, table, B, H, W, C, heads, shift, scale);
+    return check_launch("win_attn8_mfma_kernel");
+  }
   if (ws == 8 && hd == 24)
     hipLaunchKernelGGL((win_attn_kernel<8, 24>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, out, ld_out, table, B, H, W, C, heads, shift, scale);
   else if (ws == 4 && hd == 40)
