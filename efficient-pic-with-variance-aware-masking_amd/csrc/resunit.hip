@@ -321,10 +321,17 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
   stamp(2);
   // =============================================================== GEMM2: t2 = GELU(W2 * t1 + b2), 27 items
   const int px2 = wid & 3, ct2 = wid >> 2;           // one (channel tile, pixel tile) pair per wave
+  // Which of the 32 pixels of a pixel tile (two image rows x 16) a lane slot holds.  A ds_read_b128 is served in groups of
+  // 16 lanes — {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} — and the XOR swizzle of the plane image is conflict-free for
+  // 16 rows that are distinct mod 16.  With the raster order (lanes 0-15 = first row) a group straddles both image rows,
+  // whose halo rows lie 18 apart: two of its sixteen lanes collide (measured LDS conflict ratio 0.25).  So each GROUP gets
+  // one image row: 16 consecutive halo rows for every tap.  t2 rows and the epilogue use the same slot -> pixel map.
+  const int py2 = (0xF00F0FF0u >> l31) & 1;          // image row (0 / 1) inside the pixel tile
+  const int pxx2 = l31 - (l31 < 4 ? 0 : l31 < 12 ? 4 : l31 < 20 ? 8 : l31 < 28 ? 12 : 16);   // column 0..15
   f32x16 acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  const int hb2 = ((px2 * 32 + l31) >> 4) * RU_HW + (l31 & 15);          // halo row of this lane's pixel, tap (0,0)
+  const int hb2 = (px2 * 2 + py2) * RU_HW + pxx2;                        // halo row of this lane's pixel, tap (0,0)
   auto compute2 = [&](int k, const unsigned char* slot) {
     const int g = k / 9, tap = k - g * 9;
     const int ty = tap / 3, tx = tap - ty * 3;
@@ -520,8 +527,7 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
   stamp(5);
   // ---- epilogue: out = GELU(acc + b3 + x); lane = pixel, 16-byte row segments
   {
-    const int r = px2 * 32 + l31;
-    const int iy = y0 + (r >> 4), ix = x0 + (r & 15);
+    const int iy = y0 + px2 * 2 + py2, ix = x0 + pxx2;
     if (iy < u_H && ix < u_W) {
       const size_t pix = (size_t)(img * u_H + iy) * u_W + ix;
       const float* xp = P.x + pix * u_ldx;
