@@ -30,12 +30,17 @@ struct WgradArgs {
   vam_wgrad p[VAM_MAX_WGRAD_GROUP];
 };
 
+// TN x TC = 32x32 blocks of the weight tile one workgroup owns.  With a 32x32 tile every MFMA needs two vector loads (one
+// row of dY, one of X per pixel pair) and a [192->192 k5] layer reads its two tensors 25 x 6 times over (30 GB from L2 for
+// one launch, 41 TF/s); a 64x64 tile issues four MFMAs per four loads and halves that traffic.  Chosen per launch by
+// wgrad_tile(): 2x2 where both channel counts are multiples of 64, 3x1 for the 96-channel layers, 2x1 / 1x2 / 1x1 otherwise.
+template <int TN, int TC>
 __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs args) {
   __shared__ float red[WG_WAVES][32][33];
   __shared__ float redb[WG_WAVES][2][32];
   const vam_wgrad& pr = args.p[blockIdx.y];
   const int kh = pr.kh, kw = pr.kw, taps = kh * kw;
-  const int n_tiles = (pr.N + 31) / 32, c_tiles = (pr.C + 31) / 32;
+  const int n_tiles = (pr.N + 32 * TN - 1) / (32 * TN), c_tiles = (pr.C + 32 * TC - 1) / (32 * TC);
   const int per = taps * n_tiles * c_tiles;
   const int S = pr.splits > 1 ? pr.splits : 1;
   int bid = blockIdx.x;
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   bid -= split * per;
   const int tap = bid % taps;
   bid /= taps;
-  const int n0 = (bid % n_tiles) * 32, c0 = (bid / n_tiles) * 32;
+  const int n0 = (bid % n_tiles) * (32 * TN), c0 = (bid / n_tiles) * (32 * TC);
   const int ty = tap / kw, tx = tap % kw, pad_y = kh / 2, pad_x = kw / 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -59,56 +64,87 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   const float* __restrict__ x = pr.x;
   const float* __restrict__ dy = pr.dy;
   const int ld_x = pr.ld_x, ld_dy = pr.ld_dy;
-  const bool n_ok = n0 + l31 < pr.N, c_ok = c0 + l31 < pr.C;
-  const bool want_db = pr.db != nullptr && tap == 0 && c0 == 0 && pr.c_off == 0;
-  f32x16 acc;
+  bool n_ok[TN], c_ok[TC];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float bsum = 0.f;
+  for (int u = 0; u < TN; ++u) n_ok[u] = n0 + 32 * u + l31 < pr.N;
+#pragma unroll
+  for (int u = 0; u < TC; ++u) c_ok[u] = c0 + 32 * u + l31 < pr.C;
+  const bool want_db = pr.db != nullptr && tap == 0 && c0 == 0 && pr.c_off == 0;
+  f32x16 acc[TN][TC];
+#pragma unroll
+  for (int u = 0; u < TN; ++u)
+#pragma unroll
+    for (int v = 0; v < TC; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+  float bsum[TN];
+#pragma unroll
+  for (int u = 0; u < TN; ++u) bsum[u] = 0.f;
   for (long pb = p_begin + (long)wid * (2 * WG_BATCH); pb < p_end; pb += (long)WG_WAVES * 2 * WG_BATCH) {
-    float a[WG_BATCH], b[WG_BATCH];
+    float a[WG_BATCH][TN], b[WG_BATCH][TC];
 #pragma unroll
     for (int i = 0; i < WG_BATCH; ++i) {
       const long p = pb + 2 * i + lh;
-      a[i] = 0.f;
-      b[i] = 0.f;
+#pragma unroll
+      for (int u = 0; u < TN; ++u) a[i][u] = 0.f;
+#pragma unroll
+      for (int v = 0; v < TC; ++v) b[i][v] = 0.f;
       if (p < p_end) {
-        if (n_ok) a[i] = dy[p * ld_dy + n0 + l31];
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+          if (n_ok[u]) a[i][u] = dy[p * ld_dy + n0 + 32 * u + l31];
         const int bi = (int)(p / HW);
         const int r = (int)(p - (long)bi * HW);
         const int oy = r / W, ox = r - oy * W;
         const int iy = oy * stride - pad_y + ty, ix = ox * stride - pad_x + tx;
-        if (c_ok && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx)
-          b[i] = x[((long)bi * HWx + (long)iy * Wx + ix) * ld_x + c0 + l31];
+        if ((unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx) {
+          const float* xp = x + ((long)bi * HWx + (long)iy * Wx + ix) * ld_x + c0 + l31;
+#pragma unroll
+          for (int v = 0; v < TC; ++v)
+            if (c_ok[v]) b[i][v] = xp[32 * v];
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < WG_BATCH; ++i) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
-      bsum += a[i];
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+#pragma unroll
+        for (int v = 0; v < TC; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[i][v], acc[u][v], 0, 0, 0);
+        bsum[u] += a[i][u];
+      }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[r];
-  redb[wid][lh][l31] = bsum;
-  __syncthreads();
   float* part = S > 1 ? pr.workspace + (size_t)split * ((size_t)pr.N * pr.C * taps + pr.N) : nullptr;
-  for (int i = threadIdx.x; i < 32 * 32; i += WG_WAVES * 64) {
-    const int n = i >> 5, c = i & 31;
-    if (n0 + n < pr.N && c0 + c < pr.C) {
-      float v = red[0][n][c];
+  // the 32x32 blocks of the tile go through the reduction buffer one after the other (fixed order over the 8 waves)
 #pragma unroll
-      for (int k = 1; k < WG_WAVES; ++k) v += red[k][n][c];
-      if (part) part[((size_t)(n0 + n) * pr.C + c0 + c) * taps + tap] = v;
-      else pr.dw[(((long)(n0 + n) * pr.cin_total + pr.c_off + c0 + c) * kh + ty) * kw + tx] = v;
+  for (int u = 0; u < TN; ++u) {
+#pragma unroll
+    for (int v = 0; v < TC; ++v) {
+      if (u + v > 0) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][l31] = acc[u][v][r];
+      if (v == 0) redb[wid][lh][l31] = bsum[u];
+      __syncthreads();
+      const int nb = n0 + 32 * u, cb = c0 + 32 * v;
+      for (int i = threadIdx.x; i < 32 * 32; i += WG_WAVES * 64) {
+        const int n = i >> 5, c = i & 31;
+        if (nb + n < pr.N && cb + c < pr.C) {
+          float t = red[0][n][c];
+#pragma unroll
+          for (int k = 1; k < WG_WAVES; ++k) t += red[k][n][c];
+          if (part) part[((size_t)(nb + n) * pr.C + cb + c) * taps + tap] = t;
+          else pr.dw[(((long)(nb + n) * pr.cin_total + pr.c_off + cb + c) * kh + ty) * kw + tx] = t;
+        }
+      }
+      if (v == 0 && want_db && threadIdx.x < 32 && nb + threadIdx.x < pr.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) t += redb[k][0][threadIdx.x] + redb[k][1][threadIdx.x];
+        if (part) part[(size_t)pr.N * pr.C * taps + nb + threadIdx.x] = t;
+        else pr.db[nb + threadIdx.x] = t;
+      }
     }
-  }
-  if (want_db && threadIdx.x < 32 && n0 + threadIdx.x < pr.N) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < WG_WAVES; ++k) v += redb[k][0][threadIdx.x] + redb[k][1][threadIdx.x];
-    if (part) part[(size_t)pr.N * pr.C * taps + n0 + threadIdx.x] = v;
-    else pr.db[n0 + threadIdx.x] = v;
   }
 }
 
@@ -265,9 +301,20 @@ using namespace vam;
 
 extern "C" {
 
+// 32x32 blocks per workgroup tile (wgrad_kernel<TN, TC>): wide where it costs little padding
+static void wgrad_tile(const vam_wgrad& p, int* tn, int* tc) {
+  auto pad_ok = [](int n, int t) { return (double)(cdiv(n, 32 * t) * 32 * t) <= 1.15 * n; };
+  int n_ = (p.N % 96 == 0 && p.N % 64 != 0) ? 3 : (pad_ok(p.N, 2) ? 2 : 1);
+  int c_ = (n_ < 3 && pad_ok(p.C, 2)) ? 2 : 1;
+  *tn = n_;
+  *tc = c_;
+}
+
 static int wgrad_splits(const vam_wgrad& p) {
   // enough blocks to fill the chip (4 blocks of 8 waves per CU x 256 CUs, twice over), at least 2048 pixels per split
-  const long per = (long)p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32);
+  int tn, tc;
+  wgrad_tile(p, &tn, &tc);
+  const long per = (long)p.kh * p.kw * cdiv(p.N, 32 * tn) * cdiv(p.C, 32 * tc);
   const long P = (long)p.B * p.H * p.W;
   long s = (2048 + per - 1) / per;
   const long cap = P / 2048;
@@ -288,6 +335,13 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   int max_blocks = 0;
   long max_red = 0;
   double flops = 0;
+  int tn = 0, tc = 0;
+  wgrad_tile(probs[0], &tn, &tc);
+  for (int i = 1; i < n_probs; ++i) {               // one tile shape per launch: problems of a group are alike, else 1x1
+    int a_, b_;
+    wgrad_tile(probs[i], &a_, &b_);
+    if (a_ != tn || b_ != tc) { tn = 1; tc = 1; break; }
+  }
   for (int i = 0; i < n_probs; ++i) {
     const vam_wgrad& p = probs[i];
     VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
@@ -298,7 +352,7 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     VAM_REQUIRE(p.splits >= 0 && p.splits <= 256 && (p.splits <= 1 || p.workspace), "vam_conv_wgrad_group: problem %d: %d pixel splits need a workspace "
                 "(vam_conv_wgrad_plan)", i, p.splits);
     const int S = p.splits > 1 ? p.splits : 1;
-    int nb = p.kh * p.kw * cdiv(p.N, 32) * cdiv(p.C, 32) * S;
+    int nb = p.kh * p.kw * cdiv(p.N, 32 * tn) * cdiv(p.C, 32 * tc) * S;
     max_blocks = nb > max_blocks ? nb : max_blocks;
     if (S > 1) {
       const long tot = (long)p.N * p.C * p.kh * p.kw + p.N;
@@ -309,7 +363,10 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   WgradArgs wa;
   for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
   ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
+#define VAM_WG(TN_, TC_) \
+  if (tn == TN_ && tc == TC_) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
+  VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1)
+#undef VAM_WG
   if (int rc = check_launch("wgrad_kernel")) return rc;
   if (max_red > 0) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(max_red, 256) > 1024 ? 1024 : cdiv(max_red, 256), n_probs), dim3(256), 0,
