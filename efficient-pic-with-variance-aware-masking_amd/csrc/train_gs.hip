@@ -7,6 +7,7 @@
 //     window-attention backward (softmax, q/k/v and relative-position-bias gradients).
 // Formulas mirror what autograd derives for layers/layers.py:30-74, layers/gdn.py:62-75, layers/win_attention.py:84-115.
 #include "common.h"
+#include <cstdlib>
 
 namespace vam {
 
@@ -282,6 +283,217 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const float* __restric
   for (int i = lane; i < HPW * NT; i += 64) row[i] = sT[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 8 x 8 windows: the backward on the fp32 matrix pipe (round 3).  The kernel above needs 63 KB of LDS per wave (K, V, q,
+// dO and two 64 x 65 score images for the transposed pass), i.e. TWO waves per CU: 2.6 ms per launch at 32x64x64x192,
+// 21 ms of a first_train step.  Here every product is a v_mfma_f32_32x32x2_f32 chain (exact fp32, as in the forward
+// kernel csrc/win_attn.hip win_attn8_mfma_kernel, same operand / accumulator conventions) and the scores are computed in
+// BOTH orientations, so that every reduction runs over the row index of an accumulator and nothing is transposed:
+//   phase A, accumulators [key][query]:   S^T = K Qs^T,  dP^T = V dO^T  ->  P^T, row sums, dS^T (in the lane's registers:
+//            a lane holds one query);  dQs^T = K^T dS^T;  bias-table gradient (LDS adds of one wave: lane order);
+//   phase B, accumulators [query][key]:   S = Qs K^T (the same bits as S^T: the MFMA is symmetric in its operands),
+//            dP = dO V^T  ->  P, dS with the row statistics of phase A (LDS);  dV^T = dO^T P,  dK^T = Qs^T dS.
+// 384 MFMAs per (window, head); LDS 26 KB per wave (q, k, v, dO images + statistics + the bias-gradient table).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(64) void win_attn8_bwd_mfma_kernel(const float* __restrict__ qkv, int ld_qkv, const float* __restrict__ dout,
+                                                               int ld_do, float* __restrict__ dqkv, int ld_dq,
+                                                               const float* __restrict__ table, float* __restrict__ partial,
+                                                               int B, int H, int W, int C, int heads, int shift, float scale) {
+  static_assert(HD % 4 == 0 && HD <= 32, "head dim: a multiple of 4, one 32-row block");
+  constexpr int WS = 8, N = 64, KS = HD / 2, NT = (2 * WS - 1) * (2 * WS - 1);
+  __shared__ __attribute__((aligned(16))) float sQ[N * HD], sK[N * HD], sV[N * HD], sG[N * HD];
+  __shared__ __attribute__((aligned(16))) float sM[N], sI[N], sR[N];
+  __shared__ float sTab[NT], sT[NT];
+
+  const int lane = threadIdx.x, r31 = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int head = bid % heads;
+  bid /= heads;
+  const int nWx = W / WS, nWy = H / WS;
+  const int wx = bid % nWx;
+  bid /= nWx;
+  const int wy = bid % nWy;
+  const int b = bid / nWy;
+  for (int i = lane; i < NT; i += 64) { sTab[i] = table[i * heads + head]; sT[i] = 0.f; }
+
+  size_t pix[2];
+  int ti[2], tj[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int tok = 32 * i + r31;
+    ti[i] = tok >> 3;
+    tj[i] = tok & 7;
+    int oy = wy * WS + ti[i] + shift, ox = wx * WS + tj[i] + shift;
+    if (oy >= H) oy -= H;
+    if (ox >= W) ox -= W;
+    pix[i] = ((size_t)b * H + oy) * W + ox;
+  }
+  // LDS images [token][d] of q * scale, k, v, dO: half h of the wave copies the float4s d/4 = h, h+2, ...
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float* base = qkv + pix[i] * ld_qkv + head * HD;
+    const float* gb = dout + pix[i] * ld_do + head * HD;
+#pragma unroll
+    for (int d = 4 * h; d < HD; d += 8) {
+      const float4 qv = *reinterpret_cast<const float4*>(base + d);
+      const int o = (32 * i + r31) * HD + d;
+      *reinterpret_cast<float4*>(sQ + o) = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
+      *reinterpret_cast<float4*>(sK + o) = *reinterpret_cast<const float4*>(base + C + d);
+      *reinterpret_cast<float4*>(sV + o) = *reinterpret_cast<const float4*>(base + 2 * C + d);
+      *reinterpret_cast<float4*>(sG + o) = *reinterpret_cast<const float4*>(gb + d);
+    }
+  }
+  __syncthreads();
+  // operand of lane (r31, h) for k-step t: element 2t + h of token 32 i + r31
+  auto operands = [&](const float* img, float (&a)[2][KS]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < KS; ++t) a[i][t] = img[(32 * i + r31) * HD + 2 * t + h];
+  };
+  auto product = [&](f32x16 (&acc)[2][2], const float (&ra)[2][KS], const float (&cb)[2][KS]) {   // acc[i][j] = rows of a-block i x columns of b-block j
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t], cb[j][t], acc[i][j], 0, 0, 0);
+  };
+  auto rid1 = [&](int sgrid, int n) { return shift > 0 ? (sgrid < n - WS ? 0 : (sgrid < n - shift ? 1 : 2)) : 0; };
+  // token index of accumulator row e of block i on lane half h
+  auto rowtok = [&](int i, int e) { return 32 * i + 8 * (e >> 2) + 4 * h + (e & 3); };
+  // out^T[d][col token] = sum over the accumulator rows of img[row token][d] * acc[row][col]; stores float4s of d
+  auto reduce_rows = [&](const float* img, const f32x16 (&acc)[2][2], float mul, float* dst_base, int part_off) {
+    f32x16 o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float at = r31 < HD ? img[rowtok(i, e) * HD + r31] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, acc[i][j][e], o[j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* dst = dst_base + pix[j] * ld_dq + part_off + head * HD;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * h;
+        if (d < HD)
+          *reinterpret_cast<float4*>(dst + d) = make_float4(o[j][4 * g] * mul, o[j][4 * g + 1] * mul, o[j][4 * g + 2] * mul, o[j][4 * g + 3] * mul);
+      }
+    }
+  };
+
+  float opa[2][KS], opb[2][KS];
+  f32x16 aS[2][2], aD[2][2];
+  // ---------------------------------------------------------------- phase A: [key][query]
+  operands(sK, opa);
+  operands(sQ, opb);
+  product(aS, opa, opb);
+  operands(sV, opa);
+  operands(sG, opb);
+  product(aD, opa, opb);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                      // this lane's query 32 j + r31
+    const int my_rid = rid1(wy * WS + ti[j], H) * 3 + rid1(wx * WS + tj[j], W);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ui = 4 * i + (e >> 2), uj = 4 * h + (e & 3);
+        float v = aS[i][j][e] + sTab[(ti[j] - ui + WS - 1) * (2 * WS - 1) + (tj[j] - uj + WS - 1)];
+        const int urid = rid1(wy * WS + ui, H) * 3 + rid1(wx * WS + uj, W);
+        v = v + (urid != my_rid ? -100.0f : 0.0f);
+        aS[i][j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f((aS[i][j][e] - mx) * 1.4426950408889634f);
+        aS[i][j][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = aS[i][j][e] * inv;
+        aS[i][j][e] = p;
+        rs = fmaf(p, aD[i][j][e], rs);
+      }
+    rs += __shfl_xor(rs, 32);
+    if (h == 0) { sM[32 * j + r31] = mx; sI[32 * j + r31] = inv; sR[32 * j + r31] = rs; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float ds = aS[i][j][e] * (aD[i][j][e] - rs);                 // dS^T[key][query]
+        aS[i][j][e] = ds;
+        const int ui = 4 * i + (e >> 2), uj = 4 * h + (e & 3);
+        atomicAdd(sT + (ti[j] - ui + WS - 1) * (2 * WS - 1) + (tj[j] - uj + WS - 1), ds);
+      }
+  }
+  reduce_rows(sK, aS, scale, dqkv, 0);               // dq = scale * sum_key dS K   (columns = queries)
+  __syncthreads();                                   // statistics visible
+  // ---------------------------------------------------------------- phase B: [query][key]
+  operands(sQ, opa);
+  operands(sK, opb);
+  product(aS, opa, opb);
+  operands(sG, opa);
+  operands(sV, opb);
+  product(aD, opa, opb);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                      // this lane's key 32 j + r31
+    const int key_rid = rid1(wy * WS + ti[j], H) * 3 + rid1(wx * WS + tj[j], W);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q0 = 32 * i + 8 * g + 4 * h;       // queries of registers 4g .. 4g+3
+        const float4 m4 = *reinterpret_cast<const float4*>(sM + q0), i4 = *reinterpret_cast<const float4*>(sI + q0),
+                     r4 = *reinterpret_cast<const float4*>(sR + q0);
+        const float mq[4] = {m4.x, m4.y, m4.z, m4.w}, iq[4] = {i4.x, i4.y, i4.z, i4.w}, rq[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = 4 * g + c;
+          const int qi = 4 * i + g, qj = 4 * h + c;  // window coordinates of query q0 + c
+          float v = aS[i][j][e] + sTab[(qi - ti[j] + WS - 1) * (2 * WS - 1) + (qj - tj[j] + WS - 1)];
+          const int qrid = rid1(wy * WS + qi, H) * 3 + rid1(wx * WS + qj, W);
+          v = v + (key_rid != qrid ? -100.0f : 0.0f);
+          const float p = __builtin_amdgcn_exp2f((v - mq[c]) * 1.4426950408889634f) * iq[c];
+          aS[i][j][e] = p;                                                   // P[query][key]
+          aD[i][j][e] = p * (aD[i][j][e] - rq[c]);                           // dS[query][key]
+        }
+      }
+  }
+  reduce_rows(sG, aS, 1.0f, dqkv, 2 * C);            // dv = sum_query P dO     (columns = keys)
+  reduce_rows(sQ, aD, 1.0f, dqkv, C);                // dk = sum_query dS (q scale)
+  __syncthreads();                                   // (LDS adds of the bias gradient complete)
+  float* row = partial + (size_t)blockIdx.x * NT;
+  for (int i = lane; i < NT; i += 64) row[i] = sT[i];
+}
+
 // dtable[r][hg * hpw + h2] = sum over the blocks of head group hg (block id = win * groups + hg), in block order
 __global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dtable, long n_win,
                                                                int groups, int hpw, int nt, int heads) {
@@ -376,6 +588,21 @@ int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int l
   VAM_REQUIRE(nblk < (1L << 31), "vam_win_attention_bwd: grid too large");
   const size_t smem = sizeof(float) * ((size_t)4 * hpw * n * (hd + 4) + (size_t)2 * hpw * n * (n + 1) + (size_t)hpw * nt);
   hipStream_t s = (hipStream_t)stream;
+  {
+    static int mfma_env = -1;             // VAMPIC_ATTN_MFMA=0: the FMA kernel for 8 x 8 windows too (A/B measurements)
+    if (mfma_env < 0) {
+      const char* e = getenv("VAMPIC_ATTN_MFMA");
+      mfma_env = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (ws == 8 && hd == 24 && mfma_env) {
+      hipLaunchKernelGGL((win_attn8_bwd_mfma_kernel<24>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, dout, ld_do, dqkv, ld_dq, table,
+                         workspace, B, H, W, C, heads, shift, scale);
+      if (int rc_ = check_launch("win_attn8_bwd_mfma_kernel")) return rc_;
+      hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((unsigned)(heads * nt)), dim3(256), 0, s, workspace, dtable,
+                         (long)B * (H / ws) * (W / ws), heads / hpw, hpw, nt, heads);
+      return check_launch("bias_grad_reduce_kernel");
+    }
+  }
 #define VAM_ATT_BWD(WS_, HD_)                                                                                              \
   if (ws == WS_ && hd == HD_) {                                                                                            \
     static bool attr = false;                                                                                              \
