@@ -111,6 +111,8 @@ _SIGNATURES = {
     "vam_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vam_win_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "vam_attn_set_mfma": (C.c_int, [C.c_int]),
+    "vam_attn_mfma": (C.c_int, []),
     "vam_variance_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_gauss_tail": (C.c_int, [C.c_void_p, C.c_int] * 5 + [C.c_void_p, C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),

@@ -589,12 +589,7 @@ int vam_win_attention_bwd(const float* qkv, int ld_qkv, const float* dout, int l
   const size_t smem = sizeof(float) * ((size_t)4 * hpw * n * (hd + 4) + (size_t)2 * hpw * n * (n + 1) + (size_t)hpw * nt);
   hipStream_t s = (hipStream_t)stream;
   {
-    static int mfma_env = -1;             // VAMPIC_ATTN_MFMA=0: the FMA kernel for 8 x 8 windows too (A/B measurements)
-    if (mfma_env < 0) {
-      const char* e = getenv("VAMPIC_ATTN_MFMA");
-      mfma_env = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (ws == 8 && hd == 24 && mfma_env) {
+    if (ws == 8 && hd == 24 && vam_attn_mfma()) {
       hipLaunchKernelGGL((win_attn8_bwd_mfma_kernel<24>), dim3((unsigned)nblk), dim3(64), 0, s, qkv, ld_qkv, dout, ld_do, dqkv, ld_dq, table,
                          workspace, B, H, W, C, heads, shift, scale);
       if (int rc_ = check_launch("win_attn8_bwd_mfma_kernel")) return rc_;

@@ -272,6 +272,21 @@ __global__ __launch_bounds__(64) void win_attn8_mfma_kernel(const float* __restr
 
 using namespace vam;
 
+// 1 (default): 8 x 8 windows run on the fp32 matrix pipe (forward and backward); 0: the FMA kernels (A/B measurements and
+// the equivalence test); -1: follow the environment variable VAMPIC_ATTN_MFMA
+static int g_attn_mfma = -1;
+extern "C" int vam_attn_set_mfma(int mode) {
+  g_attn_mfma = mode < 0 ? -1 : (mode ? 1 : 0);
+  return VAM_OK;
+}
+extern "C" int vam_attn_mfma(void) {
+  if (g_attn_mfma < 0) {
+    const char* e = getenv("VAMPIC_ATTN_MFMA");
+    g_attn_mfma = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_attn_mfma;
+}
+
 extern "C" int vam_win_attention(const float* qkv, int ld_qkv, float* out, int ld_out, const float* table, int B,
                                  int H, int W, int C, int heads, int ws, int shift, void* stream) {
   VAM_REQUIRE(qkv && out && table && B > 0 && H > 0 && W > 0, "vam_win_attention: bad arguments");
@@ -289,12 +304,7 @@ extern "C" int vam_win_attention(const float* qkv, int ld_qkv, float* out, int l
   hipStream_t s = (hipStream_t)stream;
   double tokens = (double)B * H * W;
   ProfScope ps(VAM_FAM_ATTN, s, 4.0 * tokens * ws * ws * C, 4.0 * tokens * 4 * C);
-  static int mfma_env = -1;               // VAMPIC_ATTN_MFMA=0: the FMA kernel for 8 x 8 windows too (A/B measurements)
-  if (mfma_env < 0) {
-    const char* e = getenv("VAMPIC_ATTN_MFMA");
-    mfma_env = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (ws == 8 && hd == 24 && mfma_env) {
+  if (ws == 8 && hd == 24 && vam_attn_mfma()) {
     // one wave per (window, head): fp32 products on the matrix pipe (win_attn8_mfma_kernel)
     const long nb = (long)B * (H / ws) * (W / ws) * heads;
     VAM_REQUIRE(nb < (1L << 31), "vam_win_attention: grid too large");

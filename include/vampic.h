@@ -208,6 +208,11 @@ int vam_nhwc_to_nchw(const float* src, int ld_src, float* dst, int B, int C, int
  * table: relative_position_bias_table [(2ws-1)^2][heads].  ws in {4,8}. */
 int vam_win_attention(const float* qkv, int ld_qkv, float* out, int ld_out, const float* table,
                       int B, int H, int W, int C, int heads, int ws, int shift, void* stream);
+/* 8 x 8 windows run on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products), forward and backward;
+ * vam_attn_set_mfma(0) selects the FMA kernels instead (A/B measurements, equivalence test), -1 = follow the
+ * environment variable VAMPIC_ATTN_MFMA.  vam_attn_mfma() returns the mode in force. */
+int vam_attn_set_mfma(int mode);
+int vam_attn_mfma(void);
 
 /* ------------------------------------------------------------------ variance mask */
 /* ChannelMask.forward "point-based-std" (layers/channel_mask.py:132-151) for n_seg

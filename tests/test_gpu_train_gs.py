@@ -402,3 +402,35 @@ def test_training_step_is_reproducible_under_graph_replay(pic_model):
                 assert (g[n] - ref[n]).abs().max().item() <= 1e-6 * ref[n].abs().max().item(), (it, n)
             else:
                 assert torch.equal(g[n], ref[n]), (it, n)
+
+
+def test_matrix_pipe_attention_agrees_with_the_fma_kernels():
+    """8 x 8 windows run on the fp32 matrix pipe (csrc/win_attn.hip win_attn8_mfma_kernel, csrc/train_gs.hip
+    win_attn8_bwd_mfma_kernel): exact fp32 products like the FMA kernels they replace, in a different summation order and
+    with exp2 instead of expf — forward output and all four gradients (dq, dk, dv, d bias table) agree to 2e-6 of their
+    magnitude, with and without the cyclic shift."""
+    lib = L.load()
+    B, H, W, C_, heads, ws = 2, 16, 24, 192, 8, 8
+    qkv = ops.from_nchw(synth.normal((B, 3 * C_, H, W), 71).cuda())
+    dout = ops.from_nchw(synth.normal((B, C_, H, W), 72).cuda())
+    tab = synth.normal(((2 * ws - 1) ** 2, heads), 73, 0.5).cuda()
+    for shift in (0, 4):
+        res = {}
+        for mode in (1, 0):
+            lib.vam_attn_set_mfma(mode)
+            try:
+                out = ops.new_view(B, H, W, C_, "cuda")
+                ops.win_attention(qkv, out, tab, C_, heads, ws, shift)
+                dq = ops.new_view(B, H, W, 3 * C_, "cuda")
+                dtab = torch.zeros_like(tab)
+                wsb = torch.empty(lib.vam_win_attention_bwd_workspace(B, H, W, heads, ws) // 4, device="cuda")
+                L.check(lib.vam_win_attention_bwd(qkv.ptr, qkv.ld, dout.ptr, dout.ld, dq.ptr, dq.ld, tab.data_ptr(), dtab.data_ptr(),
+                                                  wsb.data_ptr(), B, H, W, C_, heads, ws, shift, ops.stream_ptr()), "vam_win_attention_bwd")
+                torch.cuda.synchronize()
+                res[mode] = (out.buf.clone(), dq.buf.clone(), dtab.clone())
+            finally:
+                lib.vam_attn_set_mfma(-1)
+        for a, b, what in zip(res[1], res[0], ("out", "dqkv", "dtable")):
+            assert torch.isfinite(a).all(), what
+            err = (a - b).abs().max().item()
+            assert err <= 2e-6 * max(1.0, b.abs().max().item()) * (8 if what == "dtable" else 1), (shift, what, err, b.abs().max().item())
