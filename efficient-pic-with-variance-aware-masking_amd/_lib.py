@@ -82,7 +82,10 @@ class VamResunit(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_int32), ("ldo", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
-                ("w3", C.c_void_p), ("b3", C.c_void_p)]
+                ("w3", C.c_void_p), ("b3", C.c_void_p), ("flags", C.c_int32), ("pad_", C.c_int32)]
+
+
+RESUNIT_BF16 = 1
 
 
 _SIGNATURES = {

@@ -49,7 +49,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct RuP {
-  const float* x;
+  const float* x;      // (bf16-storage problems: bf16 tensors behind these two pointers, strides in bf16 elements)
   float* out;
   const float* w1; const float* b1;
   const float* w2; const float* b2;
@@ -554,6 +554,281 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
   stamp(6);
 }
 
+// ======================================================================================================================
+// bf16-storage variant (BASELINE configs[2] "bf16", model.storage = "bf16"; conv_igemm.hip MODE 2): x, t1, t2 and the
+// output are bf16 tensors, the weights are rounded to bf16 once at pack time (vam_pack_conv_weights_bf16: 64 B per
+// (output channel, 32-channel chunk)), ONE v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulation, the
+// intermediates rounded to bf16 (nearest even) exactly where the three-launch form stores them — bit-identical to it.
+// A sixth of the matrix work and a third of the LDS bytes of the fp32 kernel: t1 / t2 rows are 192 B (34.5 KB for the
+// halo tile), a weight slab is 6 KB, the ring 18 KB -> 54 KB per workgroup, THREE workgroups per CU, so here the GELU /
+// rounding phases of one tile do run beside the MFMA and load phases of the others.  6 waves: GEMM1's 18 pairs are
+// three per wave (one pixel tile, three channel tiles), GEMM2's 12 and each half of GEMM3's 24 two per wave (one
+// channel tile, two pixel tiles).  x needs no split, so its chunks are plain 16-byte copies; the weight slabs come by
+// LDS-DMA (one 1 KB instruction per wave and slab).
+constexpr int RB_NT = 384;                        // 6 waves
+constexpr int RB_TROW = 192;                      // bytes of one t1 / t2 row: 96 channels of bf16 = three 64-byte groups
+constexpr int RB_TBYTES = RU_NHALO * RB_TROW;     // 34,560
+constexpr int RB_SLOT = 96 * 64;                  // one weight slab: 96 rows x 64 B
+constexpr int RB_LDS = RB_TBYTES + 3 * RB_SLOT + (96 + 96 + 192) * 4;   // 54,528: t1/t2 | ring | b1 b2 b3
+
+__device__ __forceinline__ unsigned rb_pk2(float lo, float hi) {         // two fp32 -> two bf16 (nearest even), lo in the low half
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ __launch_bounds__(RB_NT, 5) void resunit192_bf16_kernel(const RuArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sT = smem;                        // t1 (180 rows) / t2 (128 rows); during GEMM1: x chunks [2][192][64 B]
+  unsigned char* sR = smem + RB_TBYTES;            // weight ring, 3 slots
+  float* sBias = reinterpret_cast<float*>(smem + RB_TBYTES + 3 * RB_SLOT);
+
+  int pi = -1, t = 0;
+  {
+    const int xcd = blockIdx.x & 7;
+    int idx = blockIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < VAM_MAX_GROUP; ++i) {
+      if (i < args.nprob && pi < 0) {
+        const int T = args.tile_start[i + 1] - args.tile_start[i];
+        const int q = T >> 3, r = T & 7;
+        const int c = q + (xcd < r ? 1 : 0);
+        if (idx < c) {
+          pi = i;
+          t = xcd * q + (xcd < r ? xcd : r) + idx;
+        } else {
+          idx -= c;
+        }
+      }
+    }
+  }
+  if (pi < 0) return;
+  const RuP& P = args.p[pi];
+  const int u_H = __builtin_amdgcn_readfirstlane(P.H), u_W = __builtin_amdgcn_readfirstlane(P.W);
+  const int u_ldx = __builtin_amdgcn_readfirstlane(P.ldx), u_ldo = __builtin_amdgcn_readfirstlane(P.ldo);
+  const int tpi = P.tiles_x * P.tiles_y;
+  const int img = t / tpi;
+  const int tr = t - img * tpi;
+  const int tyi = tr / P.tiles_x;
+  const int y0 = tyi * RU_TH, x0 = (tr - tyi * P.tiles_x) * RU_TW;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  auto desc = [&](const void* q) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)), 0, 0x7FFFFFFF, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_x = desc(P.x), r_w1 = desc(P.w1), r_w2 = desc(P.w2), r_w3 = desc(P.w3);
+  if (tid < 96) sBias[tid] = P.b1[tid];
+  else if (tid < 192) sBias[tid] = P.b2[tid - 96];
+  else sBias[tid] = P.b3[tid - 192];               // 192 threads left = the 192 biases of the last layer
+
+  // ---- GEMM1 staging roles: x units (8 channels = 16 B) tid and tid + 384 of the 768 of a chunk; W1 unit tid of 384
+  unsigned xoff[2];
+  int xst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * RB_NT;
+    const int row = u >> 2, g = u & 3;
+    const int hy = row / RU_HW, hx = row - hy * RU_HW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool in = row < RU_NHALO && (unsigned)iy < (unsigned)u_H && (unsigned)ix < (unsigned)u_W;
+    xoff[i] = in ? (unsigned)(((img * u_H + iy) * u_W + ix) * u_ldx * 2 + g * 16) : 0x80000000u;
+    xst[i] = row * 64 + ((g ^ ((row >> 2) & 3)) << 4);
+  }
+  const int wrow = tid >> 2, wc = tid & 3;
+  const unsigned wgo = (unsigned)(tid * 16);
+  const int wlo = wrow * 64 + ((wc ^ ((wrow >> 2) & 3)) << 4);
+  // LDS-DMA of a slab: instruction `wid` of six; lane -> LDS unit wid*64 + lane = (row, physical chunk c')
+  unsigned dgo;
+  {
+    const int u = wid * 64 + lane;
+    const int row = u >> 2, cp = u & 3;
+    dgo = (unsigned)((row * 4 + (cp ^ ((row >> 2) & 3))) * 16);
+  }
+  auto dma_slab = [&](const __amdgpu_buffer_rsrc_t& r, unsigned slab_byte, int slot) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(sR + slot * RB_SLOT + wid * 1024), 16, (int)dgo,
+                                             (int)slab_byte, 0, 0);
+  };
+  const int rsw = (l31 >> 2) & 3;
+  const int fsub[2] = {((lh ^ rsw) << 4), (((2 + lh) ^ rsw) << 4)};
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+  // =============================================================== GEMM1: wave = pixel tile wid, channel tiles 0..2
+  f32x16 acc1[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[q][r] = 0.f;
+  {
+    u32x4 xr0[2], xr1[2], wr0, wr1;
+    auto gload1 = [&](int k, u32x4 (&xr)[2], u32x4& wr) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(xoff[i] + (unsigned)k * 64u), 0, 0);
+      wr = __builtin_amdgcn_raw_buffer_load_b128(r_w1, (int)(wgo + (unsigned)k * (unsigned)RB_SLOT), 0, 0);
+    };
+    auto sstore1 = [&](int buf, const u32x4 (&xr)[2], const u32x4& wr) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(sT + buf * (192 * 64) + xst[i]) = xr[i];
+      *reinterpret_cast<u32x4*>(sR + buf * RB_SLOT + wlo) = wr;
+    };
+    auto compute1 = [&](int buf) {
+      const unsigned char* pb = sT + buf * (192 * 64) + (wid * 32 + l31) * 64;
+      const unsigned char* wb = sR + buf * RB_SLOT + l31 * 64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 p = *reinterpret_cast<const bf16x8*>(pb + fsub[ks]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + q * (32 * 64) + fsub[ks]);
+          acc1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, p, acc1[q], 0, 0, 0);
+        }
+      }
+    };
+    constexpr int K1 = RU_C / 32;
+    gload1(0, xr0, wr0);
+    gload1(1, xr1, wr1);
+    sstore1(0, xr0, wr0);
+    gload1(2, xr0, wr0);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < K1; k += 2) {
+      sstore1(1, xr1, wr1);
+      if (k + 3 < K1) gload1(k + 3, xr1, wr1);
+      compute1(0);
+      __syncthreads();
+      if (k + 2 < K1) sstore1(0, xr0, wr0);
+      if (k + 4 < K1) gload1(k + 4, xr0, wr0);
+      compute1(1);
+      __syncthreads();
+    }
+  }
+  auto slab2 = [](int k) -> unsigned { const int g = k / 9, tap = k - g * 9; return (unsigned)((tap * 3 + g) * 96) * 64u; };
+  auto slab3 = [](int k) -> unsigned { return (unsigned)((k >> 1) * 192 + (k & 1) * 96) * 64u; };
+  dma_slab(r_w2, slab2(0), 0);
+  dma_slab(r_w2, slab2(1), 1);
+  // ---- t1: lane = halo row wid*32 + l31, registers 4j..4j+3 of channel tile q = channels q*32 + 8j + 4lh + 0..3
+  {
+    const int row = wid * 32 + l31;
+    const int hy = row / RU_HW, hx = row - hy * RU_HW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool in = (unsigned)iy < (unsigned)u_H && (unsigned)ix < (unsigned)u_W;
+    if (row < RU_NHALO) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 bb = *reinterpret_cast<const float4*>(sBias + q * 32 + 8 * j + 4 * lh);
+          float v[4] = {acc1[q][4 * j] + bb.x, acc1[q][4 * j + 1] + bb.y, acc1[q][4 * j + 2] + bb.z, acc1[q][4 * j + 3] + bb.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = in ? ru_gelu(v[i]) : 0.f;
+          *reinterpret_cast<uint2*>(sT + row * RB_TROW + q * 64 + ((j ^ ((row >> 2) & 3)) << 4) + lh * 8) =
+              make_uint2(rb_pk2(v[0], v[1]), rb_pk2(v[2], v[3]));
+        }
+    }
+  }
+  // =============================================================== GEMM2 / GEMM3: wave = channel tile wid % 3, pixel tiles 2 (wid / 3) + {0, 1}
+  const int ctw = wid % 3, pxp = (wid / 3) * 2;
+  const int py2 = (0xF00F0FF0u >> l31) & 1;        // slot -> pixel map of a pixel tile: one image row per ds_read_b128 lane group
+  const int pxx2 = l31 - (l31 < 4 ? 0 : l31 < 12 ? 4 : l31 < 20 ? 8 : l31 < 28 ? 12 : 16);
+  f32x16 acc2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+#define RB_BAR(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  {
+    int hb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) hb[q] = ((pxp + q) * 2 + py2) * RU_HW + pxx2;
+    int slot = 0;
+#pragma unroll 1
+    for (int k = 0; k < 27; ++k) {
+      if (k + 1 < 27) RB_BAR(1); else RB_BAR(0);   // slab k landed everywhere (slab k+1 may be in flight); slab k-1's readers are done
+      if (k + 2 < 27) dma_slab(r_w2, slab2(k + 2), slot >= 1 ? slot - 1 : slot + 2);
+      const int g = k / 9, tap = k - g * 9;
+      const int toff = (tap / 3) * RU_HW + (tap % 3);
+      const unsigned char* wb = sR + slot * RB_SLOT + (ctw * 32 + l31) * 64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + fsub[ks]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int hrow = hb[q] + toff;
+          const bf16x8 p = *reinterpret_cast<const bf16x8*>(sT + hrow * RB_TROW + g * 64 + (((2 * ks + lh) ^ ((hrow >> 2) & 3)) << 4));
+          acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, p, acc2[q], 0, 0, 0);
+        }
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // all reads of t1 and of the ring are done
+  dma_slab(r_w3, slab3(0), 0);
+  dma_slab(r_w3, slab3(1), 1);
+  // ---- t2 over t1 (rows = pixel-tile slots)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (pxp + q) * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 bb = *reinterpret_cast<const float4*>(sBias + 96 + ctw * 32 + 8 * j + 4 * lh);
+      const float v0 = ru_gelu(acc2[q][4 * j] + bb.x), v1 = ru_gelu(acc2[q][4 * j + 1] + bb.y), v2 = ru_gelu(acc2[q][4 * j + 2] + bb.z),
+                  v3 = ru_gelu(acc2[q][4 * j + 3] + bb.w);
+      *reinterpret_cast<uint2*>(sT + row * RB_TROW + ctw * 64 + ((j ^ rsw) << 4) + lh * 8) = make_uint2(rb_pk2(v0, v1), rb_pk2(v2, v3));
+    }
+  }
+  // =============================================================== GEMM3: items (g, half); accumulators [half][pixel tile]
+  f32x16 acc3[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[a][q][r] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k + 1 < 6) RB_BAR(1); else RB_BAR(0);
+    if (k + 2 < 6) dma_slab(r_w3, slab3(k + 2), (k + 2) % 3);
+    const unsigned char* wb = sR + (k % 3) * RB_SLOT + (ctw * 32 + l31) * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + fsub[ks]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bf16x8 p = *reinterpret_cast<const bf16x8*>(sT + ((pxp + q) * 32 + l31) * RB_TROW + (k >> 1) * 64 + fsub[ks]);
+        acc3[k & 1][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, p, acc3[k & 1][q], 0, 0, 0);
+      }
+    }
+  }
+#undef RB_BAR
+  // ---- epilogue: out = bf16( GELU((acc + b3) + x) ); lane = pixel, four channels = 8 bytes
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int iy = y0 + (pxp + q) * 2 + py2, ix = x0 + pxx2;
+    if (iy < u_H && ix < u_W) {
+      const size_t pix = (size_t)(img * u_H + iy) * u_W + ix;
+      const unsigned short* xp = reinterpret_cast<const unsigned short*>(P.x) + pix * u_ldx;
+      unsigned short* op = reinterpret_cast<unsigned short*>(P.out) + pix * u_ldo;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = (a * 3 + ctw) * 32 + 8 * j + 4 * lh;
+          const uint2 xu = *reinterpret_cast<const uint2*>(xp + ch);
+          const float4 bb = *reinterpret_cast<const float4*>(sBias + 192 + ch);
+          const float x0f = __uint_as_float(xu.x << 16), x1f = __uint_as_float(xu.x & 0xFFFF0000u), x2f = __uint_as_float(xu.y << 16),
+                      x3f = __uint_as_float(xu.y & 0xFFFF0000u);
+          const float o0 = ru_gelu((acc3[a][q][4 * j] + bb.x) + x0f), o1 = ru_gelu((acc3[a][q][4 * j + 1] + bb.y) + x1f),
+                      o2 = ru_gelu((acc3[a][q][4 * j + 2] + bb.z) + x2f), o3 = ru_gelu((acc3[a][q][4 * j + 3] + bb.w) + x3f);
+          *reinterpret_cast<uint2*>(op + ch) = make_uint2(rb_pk2(o0, o1), rb_pk2(o2, o3));
+        }
+    }
+  }
+}
+
 static long long* g_ru_dbg = nullptr;
 static int g_ru_dma = -1;   // 1 = weight slabs by LDS-DMA through the three-slot ring (default), 0 = register-staged, two LDS
                             // buffers (VAMPIC_RU_DMA=0: the A/B arm); -1 = not chosen yet
@@ -584,7 +859,8 @@ size_t vam_resunit_struct_size(void) { return sizeof(vam_resunit); }
 
 int vam_resunit_group(const vam_resunit* probs, int nprob, void* stream) {
   VAM_REQUIRE(probs && nprob >= 1 && nprob <= VAM_MAX_GROUP, "vam_resunit_group: 1..%d problems", VAM_MAX_GROUP);
-  VAM_REQUIRE(vam_conv_get_mode() == 1, "vam_resunit_group: the fused residual unit is built for the split-operand mode");
+  const bool bf16 = (probs[0].flags & VAM_RESUNIT_BF16) != 0;
+  VAM_REQUIRE(bf16 || vam_conv_get_mode() == 1, "vam_resunit_group: the fp32 fused residual unit is built for the split-operand mode");
   RuArgs ga;
   ga.dbg = g_ru_dbg;
   ga.nprob = nprob;
@@ -594,13 +870,14 @@ int vam_resunit_group(const vam_resunit* probs, int nprob, void* stream) {
     const vam_resunit& c = probs[i];
     RuP& p = ga.p[i];
     VAM_REQUIRE(c.C == RU_C, "resunit[%d]: C = %d (this build fuses C = %d units)", i, c.C, RU_C);
+    VAM_REQUIRE(((c.flags & VAM_RESUNIT_BF16) != 0) == bf16 && (c.flags & ~VAM_RESUNIT_BF16) == 0, "resunit[%d]: a group is all fp32 or all bf16 storage (flags 0x%x)", i, c.flags);
     VAM_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0, "resunit[%d]: bad extent", i);
     VAM_REQUIRE(c.x && c.out && c.w1 && c.b1 && c.w2 && c.b2 && c.w3 && c.b3, "resunit[%d]: null pointer", i);
     VAM_REQUIRE(c.x != c.out, "resunit[%d]: in-place is not supported (neighbouring tiles read the halo)", i);
-    VAM_REQUIRE(c.ldx >= c.C && c.ldo >= c.C && c.ldx % 4 == 0 && c.ldo % 4 == 0, "resunit[%d]: pixel strides", i);
+    VAM_REQUIRE(c.ldx >= c.C && c.ldo >= c.C && c.ldx % (bf16 ? 8 : 4) == 0 && c.ldo % (bf16 ? 8 : 4) == 0, "resunit[%d]: pixel strides", i);
     auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     VAM_REQUIRE(al(c.x) && al(c.out) && al(c.w1) && al(c.w2) && al(c.w3) && al(c.b1) && al(c.b2) && al(c.b3), "resunit[%d]: pointers must be 16-byte aligned", i);
-    VAM_REQUIRE((double)c.B * c.H * c.W * c.ldx * 4.0 < 2147483648.0, "resunit[%d]: input spans 2 GiB or more (split the batch)", i);
+    VAM_REQUIRE((double)c.B * c.H * c.W * c.ldx * (bf16 ? 2.0 : 4.0) < 2147483648.0, "resunit[%d]: input spans 2 GiB or more (split the batch)", i);
     p.x = c.x; p.out = c.out; p.w1 = c.w1; p.b1 = c.b1; p.w2 = c.w2; p.b2 = c.b2; p.w3 = c.w3; p.b3 = c.b3;
     p.ldx = c.ldx; p.ldo = c.ldo; p.B = c.B; p.H = c.H; p.W = c.W;
     p.tiles_x = (c.W + RU_TW - 1) / RU_TW;
@@ -609,7 +886,7 @@ int vam_resunit_group(const vam_resunit* probs, int nprob, void* stream) {
     total += c.B * p.tiles_x * p.tiles_y;
     const double px = (double)c.B * c.H * c.W;
     flops += 2.0 * px * (double)(c.C * (c.C / 2) * 2 + (c.C / 2) * (c.C / 2) * 9);
-    bytes += 4.0 * px * 2.0 * c.C;
+    bytes += (bf16 ? 2.0 : 4.0) * px * 2.0 * c.C;
   }
   for (int i = nprob; i <= VAM_MAX_GROUP; ++i) ga.tile_start[i] = total;
   if (g_ru_dma < 0) {
@@ -621,6 +898,15 @@ int vam_resunit_group(const vam_resunit* probs, int nprob, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set[2] = {false, false};
   ProfScope ps(VAM_FAM_CONV, s, flops, bytes);
+  if (bf16) {
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute((const void*)resunit192_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS);
+      attr16 = true;
+    }
+    hipLaunchKernelGGL(resunit192_bf16_kernel, dim3(8 * per_xcd), dim3(RB_NT), RB_LDS, s, ga);
+    return check_launch("resunit192_bf16_kernel");
+  }
   if (g_ru_dma) {
     if (!attr_set[1]) {
       (void)hipFuncSetAttribute((const void*)resunit192_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RU_LDS);

@@ -357,11 +357,13 @@ def lower_residual_units(plan: Plan, mods: Sequence[Ly.ResidualUnit], xs: Sequen
     """out = GELU(conv(x) + x)  (layers/layers.py:43-48), K units in lockstep.  Shapes with a fused kernel
     (csrc/resunit.hip) take ONE launch per group of units, both C/2-channel intermediates staying in LDS; the rest
     run as three grouped conv launches — the same arithmetic, bit for bit."""
-    if all(ops.resunit_supported(x) for x in xs) and not plan.act16:
+    if all(ops.resunit_supported(x) for x in xs) and len({type(x) for x in xs}) == 1:
+        b16 = isinstance(xs[0], ops.View16)           # bf16-storage mode: bf16 tensors, bf16-packed weights
         outs = [plan.buf(x.B, x.H, x.W, x.C) for x in xs]
-        plan.resunit([ops.resunit_problem(m.conv[0].packed(), m.conv[2].packed(), m.conv[4].packed(), x, o)
-                      for m, x, o in zip(mods, xs, outs)])
-        return outs
+        if all(type(o) is type(x) for o, x in zip(outs, xs)):
+            plan.resunit([ops.resunit_problem(m.conv[0].packed(b16), m.conv[2].packed(b16), m.conv[4].packed(b16), x, o)
+                          for m, x, o in zip(mods, xs, outs)])
+            return outs
     fin = [dict(act=L.ACT_GELU, pre=x) for x in xs]
     return lower_stacks(plan, [m.conv for m in mods], [[x] for x in xs], [None] * len(mods), fin)
 

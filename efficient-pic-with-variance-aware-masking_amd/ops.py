@@ -357,28 +357,37 @@ def conv_group(problems: Sequence[L.VamConv]):
 
 
 # --------------------------------------------------------------------------- fused residual unit
-def resunit_supported(x: View) -> bool:
-    """A fused kernel exists for this unit's shape (csrc/resunit.hip: fp32 tensors, split-operand mode, C = 192)."""
-    if type(x) is not View or not split_mode() or os.environ.get("VAMPIC_FUSED_RU", "1") == "0":
+def resunit_supported(x) -> bool:
+    """A fused kernel exists for this unit's shape (csrc/resunit.hip: C = 192; fp32 tensors in the split-operand mode, or
+    bf16-stored tensors of the bf16-storage mode)."""
+    if os.environ.get("VAMPIC_FUSED_RU", "1") == "0":
+        return False
+    if type(x) is View:
+        if not split_mode():
+            return False
+    elif type(x) is not View16:
         return False
     return bool(L.load().vam_resunit_supported(x.C, x.H, x.W))
 
 
-def resunit_problem(p1: Packed, p2: Packed, p3: Packed, x: View, out: View) -> "L.VamResunit":
+def resunit_problem(p1: Packed, p2: Packed, p3: Packed, x, out) -> "L.VamResunit":
     """One ResidualUnit (layers/layers.py:30-48) as a single launch; p1 / p2 / p3 are the ordinary packed weights of
-    its 1x1 (C -> C/2), 3x3 (C/2 -> C/2) and 1x1 (C/2 -> C) convolutions."""
-    assert type(x) is View and type(out) is View, "the fused residual unit reads and writes fp32 NHWC tensors"
+    its 1x1 (C -> C/2), 3x3 (C/2 -> C/2) and 1x1 (C/2 -> C) convolutions — bf16-packed ones (``m.packed(True)``) when
+    x / out are bf16-stored tensors."""
+    b16 = type(x) is View16
+    assert type(out) is type(x) and type(x) in (View, View16), "the fused residual unit reads and writes fp32 or bf16 NHWC tensors"
     assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
     C_ = x.C
     assert (p1.kh, p1.cin, p1.n) == (1, C_, C_ // 2) and (p2.kh, p2.kw, p2.cin, p2.n, p2.stride) == (3, 3, C_ // 2, C_ // 2, 1) and \
         (p3.kh, p3.cin, p3.n) == (1, C_ // 2, C_), "residual unit: conv1x1(C, C/2), conv3x3(C/2, C/2), conv1x1(C/2, C)"
-    assert not (p1.w16 or p2.w16 or p3.w16) and p1.b is not None and p2.b is not None and p3.b is not None
+    assert p1.w16 == p2.w16 == p3.w16 == b16 and p1.b is not None and p2.b is not None and p3.b is not None
     c = L.VamResunit()
     c.x, c.out, c.ldx, c.ldo = x.ptr, out.ptr, x.ld, out.ld
     c.B, c.H, c.W, c.C = x.B, x.H, x.W, C_
     c.w1, c.b1 = p1.w.data_ptr(), p1.b.data_ptr()
     c.w2, c.b2 = p2.w.data_ptr(), p2.b.data_ptr()
     c.w3, c.b3 = p3.w.data_ptr(), p3.b.data_ptr()
+    c.flags = L.RESUNIT_BF16 if b16 else 0
     return c
 
 

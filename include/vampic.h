@@ -183,7 +183,13 @@ typedef struct vam_resunit {
   const float* w1; const float* b1;   /* conv[0]: 1x1 C   -> C/2 */
   const float* w2; const float* b2;   /* conv[2]: 3x3 C/2 -> C/2 */
   const float* w3; const float* b3;   /* conv[4]: 1x1 C/2 -> C   */
+  int32_t flags;            /* 0, or VAM_RESUNIT_BF16: bf16-storage mode (BASELINE configs[2]) — x / out are bf16 NHWC
+                               tensors (ldx / ldo count bf16 elements, multiples of 8), w1..w3 come from
+                               vam_pack_conv_weights_bf16, biases stay fp32; bit-identical to three vam_conv_group launches
+                               with VAM_CONV_W_BF16 | IN_BF16 | OUT_BF16 [| AUX_BF16] */
+  int32_t pad_;
 } vam_resunit;
+#define VAM_RESUNIT_BF16 1
 size_t vam_resunit_struct_size(void);
 int vam_resunit_supported(int C, int H, int W);
 int vam_resunit_group(const vam_resunit* problems, int n_problems, void* stream);

@@ -76,6 +76,41 @@ def test_bf16_gdn_and_deconv():
     assert float((gy - ref_y).abs().max()) <= 0.05 * float(ref_y.abs().max())
 
 
+@pytest.mark.parametrize("hw,batch", [((16, 16), 2), ((24, 40), 2), ((13, 21), 1), ((64, 64), 3)])
+def test_fused_residual_unit_bf16_storage_is_bit_identical(hw, batch, monkeypatch):
+    """csrc/resunit.hip resunit192_bf16_kernel: a ResidualUnit on bf16-stored tensors as ONE launch (t1 / t2 rounded to
+    bf16 in LDS exactly where the three-launch form stores them).  Bit-identical to three bf16 conv launches, ragged image
+    sizes included."""
+    from vampic import engine
+    m = Ly.ResidualUnit(192).cuda()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 31))
+    x = synth.normal((batch, 192) + hw, 32)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VAMPIC_FUSED_RU", fused)
+        xv = ops.new_view16(batch, hw[0], hw[1], 192)
+        xv.buf.copy_(x.cuda().permute(0, 2, 3, 1))
+        assert ops.resunit_supported(xv) == (fused == "1")
+        plan = engine.Plan("cuda")
+        plan.act16, plan.act16_min_hw = True, 1
+        o = engine.lower_residual_units(plan, [m], [xv])[0]
+        assert isinstance(o, ops.View16) and len(plan.steps) == (1 if fused == "1" else 3)
+        plan.run()
+        torch.cuda.synchronize()
+        outs[fused] = o.buf.clone()
+    monkeypatch.delenv("VAMPIC_FUSED_RU")
+    a, b = outs["1"].float(), outs["0"].float()
+    assert torch.isfinite(a).all()
+    assert torch.equal(outs["1"], outs["0"]), f"{(a != b).sum().item()} of {a.numel()} elements differ, max {(a - b).abs().max().item():.3e}"
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with O.bf16_storage(min_hw=1):
+        t = O._st(F.gelu(F.conv2d(q(x), q(sd["conv.0.weight"]), sd["conv.0.bias"])))
+        t = O._st(F.gelu(F.conv2d(t, q(sd["conv.2.weight"]), sd["conv.2.bias"], padding=1)))
+        ref = O._st(F.gelu(F.conv2d(t, q(sd["conv.4.weight"]), sd["conv.4.bias"]) + q(x)))
+    got = outs["1"].permute(0, 3, 1, 2).float().cpu()
+    assert float((got - ref).abs().max()) <= 0.03 * float(ref.abs().max())      # intermediates one bf16 ulp apart propagate
+
+
 def test_bf16_storage_model_vs_emulation_and_fp32(gpu_model):
     """forward_single_quality with storage = "bf16" on 2 x 256 x 256: (a) against the oracle's bf16 emulation (same
     rounding points; both sides round at bf16 boundaries, so single elements may sit one ulp apart and cascade: the
