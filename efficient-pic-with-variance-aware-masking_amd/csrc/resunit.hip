@@ -332,6 +332,18 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
   const int hb2 = (px2 * 2 + py2) * RU_HW + pxx2;                        // halo row of this lane's pixel, tap (0,0)
+  // identity (x at this lane's pixel, the channels of its two GEMM3 accumulators): requested when GEMM2 is done
+  float4 xv[2][4];
+  const int oiy = y0 + px2 * 2 + py2, oix = x0 + pxx2;
+  const bool opix_ok = oiy < u_H && oix < u_W;
+  const size_t opix = (size_t)(img * u_H + (opix_ok ? oiy : 0)) * u_W + (opix_ok ? oix : 0);
+  auto load_identity = [&]() {
+    const float* xp = P.x + opix * u_ldx;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[q][j] = *reinterpret_cast<const float4*>(xp + (q * 3 + ct2) * 32 + 8 * j + 4 * lh);
+  };
   auto compute2 = [&](int k, const unsigned char* slot) {
     const int g = k / 9, tap = k - g * 9;
     const int ty = tap / 3, tx = tap - ty * 3;
@@ -408,7 +420,8 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
     }
     mma(acc2, pA, wA);                                 // item 26
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all reads of t1 and of the ring are done
-    dma_slab(r_w3, slab3(0), 0);
+    load_identity();                                   // (ahead of the LDS-DMA instructions: the first GEMM3 barrier covers them,
+    dma_slab(r_w3, slab3(0), 0);                       //  and their latency runs under the t2 conversion instead of the epilogue)
     dma_slab(r_w3, slab3(1), 1);
   } else {
     gloadw(r_w2, slab2(0), wra);
@@ -428,6 +441,7 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
       compute2(k + 1, sR + RU_SLOT);
       __syncthreads();
     }
+    load_identity();
     gloadw(r_w3, slab3(0), wra);
     gloadw(r_w3, slab3(1), wrb);
   }
@@ -526,28 +540,20 @@ __global__ __launch_bounds__(RU_NT, 3) void resunit192_kernel(const RuArgs args)
 
   stamp(5);
   // ---- epilogue: out = GELU(acc + b3 + x); lane = pixel, 16-byte row segments
-  {
-    const int iy = y0 + px2 * 2 + py2, ix = x0 + pxx2;
-    if (iy < u_H && ix < u_W) {
-      const size_t pix = (size_t)(img * u_H + iy) * u_W + ix;
-      const float* xp = P.x + pix * u_ldx;
-      float* op = P.out + pix * u_ldo;
+  if (opix_ok) {
+    float* op = P.out + opix * u_ldo;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float4 xv[4];
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(xp + (q * 3 + ct2) * 32 + 8 * j + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ch = (q * 3 + ct2) * 32 + 8 * j + 4 * lh;
-          const float4 bb = *reinterpret_cast<const float4*>(P.b3 + ch);
-          float4 o;
-          o.x = ru_gelu((acc3[q][4 * j] + bb.x) + xv[j].x);
-          o.y = ru_gelu((acc3[q][4 * j + 1] + bb.y) + xv[j].y);
-          o.z = ru_gelu((acc3[q][4 * j + 2] + bb.z) + xv[j].z);
-          o.w = ru_gelu((acc3[q][4 * j + 3] + bb.w) + xv[j].w);
-          *reinterpret_cast<float4*>(op + ch) = o;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int ch = (q * 3 + ct2) * 32 + 8 * j + 4 * lh;
+        const float4 bb = *reinterpret_cast<const float4*>(P.b3 + ch);
+        float4 o;
+        o.x = ru_gelu((acc3[q][4 * j] + bb.x) + xv[q][j].x);
+        o.y = ru_gelu((acc3[q][4 * j + 1] + bb.y) + xv[q][j].y);
+        o.z = ru_gelu((acc3[q][4 * j + 2] + bb.z) + xv[q][j].z);
+        o.w = ru_gelu((acc3[q][4 * j + 3] + bb.w) + xv[q][j].w);
+        *reinterpret_cast<float4*>(op + ch) = o;
       }
     }
   }
