@@ -79,6 +79,12 @@ def main():
     for _ in range(max(a.warmup, 1)):
         c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
     sync()
+    # The plans hold ~1e6 long-lived Python objects (problem structs, views): a full (generation-2) pass of the cyclic
+    # collector over them takes ~150 ms and one falls inside a 10-step window (measured: scratch/ft_steps.py).
+    # Park what exists now in the permanent generation, as long-running training loops do.
+    import gc
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
