@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+POWER_LIMITED_SPLIT_TFLOPS = 266.8  # profiles/r03_mfma_shapes.txt: MFMA-only inner loop on Gaussian operands, fp32-equivalent
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (not the 2:1-sparsity figure)
 BF16X3_PRODUCTS = 6                # bf16 partial products per fp32 multiply-add in the split-operand kernel
 FLOP_PER_PIXEL = 1_784_853         # BASELINE.md §2, forward_single_quality 0 < q <= 10
@@ -270,6 +271,15 @@ def main():
                 cls[k] = {"ms_per_step": round(v["ms"] / psteps, 3), "launches_per_step": v["launches"] // psteps,
                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
         roof["classes"] = cls
+        if split:
+            # NOT measured by this run: the matrix pipe's rate on Gaussian operands, where the clock is power-limited.
+            # scratch/probe/mfma_shapes.hip runs the consumer wave's inner loop alone (LDS fragment reads + the six
+            # products of a 128 x 192 tile, no global traffic) on all 256 CUs: 1,600 TF/s executed with Gaussian planes,
+            # 2,360 TF/s with all-zero planes (profiles/r03_mfma_shapes.txt).  `frac` above stays against the nominal peak.
+            roof["power_limited_ceiling"] = {
+                "tflops": POWER_LIMITED_SPLIT_TFLOPS, "frac": round(achieved / POWER_LIMITED_SPLIT_TFLOPS, 4),
+                "source": "committed probe log profiles/r03_mfma_shapes.txt (1,600 TF/s executed bf16 MFMA / 6 products; "
+                          "not measured by this run)"}
         gms = classes["g_a"]["ms"] + classes["g_s"]["ms"]
         gfl = classes["g_a"]["flops"] + classes["g_s"]["flops"]
         if gms > 0:
