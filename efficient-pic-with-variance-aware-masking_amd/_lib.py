@@ -75,6 +75,7 @@ class VamConv(C.Structure):
         ("act", C.c_int32),
         ("flags", C.c_int32),
         ("pre", VamAux), ("mul", VamAux), ("post", VamAux), ("post2", VamAux),
+        ("in_amax", C.c_void_p * VAM_MAX_SEG), ("out_amax", C.c_void_p),
     ]
 
 
@@ -125,6 +126,7 @@ _SIGNATURES = {
     "vam_dequantize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vam_absmax": (C.c_int, [C.POINTER(VamSeg), C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_sqdiff_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_eb_forward_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),
     "vam_ssim_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -38,6 +38,8 @@ namespace vam {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct ConvP {
   const float* seg_ptr[VAM_MAX_SEG];
@@ -60,6 +62,8 @@ struct ConvP {
   const float* post2;
   int ld_pre, ld_mul, ld_post, ld_post2;
   int tiles_n;
+  const int* in_amax[VAM_MAX_SEG];   // MODE 3: per input segment, a device cell holding the bits of an upper bound of max |x| (nullptr: unused)
+  int* out_amax;        // any mode: if set, the epilogue folds max |stored value| into this cell (integer atomicMax on the float's bits)
 };
 
 constexpr int VAM_CONVI_DUAL = 1 << 29;     // internal ConvP flag: 16-channel input, two taps share one 32-channel K chunk (split-operand mode)
@@ -108,8 +112,9 @@ constexpr int PK = 16;  // packing granularity of the weight buffer along K
 // (Tried on top and measured no better, so not kept: 8 consumer waves (4x2) beside 4 loaders on the 128x192 / 128x128
 // tiles — two consumers per SIMD to cover each other's operand-read latency: 2350 vs 2287 us on the 192->192 5x5 layer.)
 template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
-__global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <= 192) ? 4 : 2) : ((MODE == 1 && BM == 128 && BN == 128) ? 3 : 2)) void conv_igemm_kernel(const GroupArgs args) {
-  static_assert(SPEC == 0 || MODE == 1, "wave specialisation is built for the split-operand mode");
+__global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <= 192) ? 4 : 2) : (((MODE == 1 || MODE == 3) && BM == 128 && BN == 128) ? 3 : 2)) void conv_igemm_kernel(const GroupArgs args) {
+  static_assert(SPEC == 0 || MODE == 1 || MODE == 3, "wave specialisation is built for the split-operand modes");
+  static_assert(MODE != 3 || AIN == 0, "MODE 3 (fp16x2) takes fp32 inputs");
   static_assert(MODE != 2 || AIN <= 1, "MODE 2: AIN 0 = fp32 input rounded while staged, 1 = bf16 input");
   constexpr int NT = WGM * WGN * 64;         // threads of one role group (= threads per block without SPEC)
   constexpr int NTC = NT;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   const int n_taps = u_kh * u_kw;
   // 16-channel inputs (the space-to-depth RGB layer): a 32-channel K chunk would be half zeros, so two consecutive taps
   // share one (units 0-1 of a row: tap 2c, units 2-3: tap 2c+1); the weights are packed the same way
-  const bool dual = MODE == 1 && (P.flags & VAM_CONVI_DUAL) != 0;
+  const bool dual = (MODE == 1 || MODE == 3) && (P.flags & VAM_CONVI_DUAL) != 0;
   const int n_chunks = dual ? (n_taps + 1) / 2 : n_taps * u_Kc;        // Kc = K chunks of BK per tap
   // fp32 NHWC outputs with fp32 epilogue operands leave straight from the accumulators (epilogue, "direct" path) in the
   // one configuration where that measured faster (see there)
@@ -412,16 +417,26 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       __syncthreads();
     }
 
-  } else if constexpr (MODE == 1) {
-    // =============================================================== MODE 1: bf16x3 operands
+  } else if constexpr (MODE == 1 || MODE == 3) {
+    // =============================================================== MODE 1: bf16x3 operands   (MODE 3: fp16x2, below)
     // LDS row (one pixel / one output channel, 32 input channels of one tap): 12 chunks of 16 B = 192 B, no padding;
     //   logical chunk (p*4 + g) = 8 bf16 of plane p (0 hi, 1 mid, 2 lo) and channel group g (channels 8g..8g+7),
     //   stored at chunk p*4 + (g ^ ((row >> 2) & 3)).  An MFMA k-step s (16 channels) takes group 2s from lanes 0-31
     //   and 2s+1 from lanes 32-63.  With the XOR term both the staging writes (16 lanes = 4 rows x 4 groups of one
     //   plane) and the operand reads (16 rows of one chunk) touch every LDS bank exactly once.
-    constexpr int RS = 48;
+    // MODE 3 (fp16x2, opt-in): x 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h) (both round-to-nearest; 22 of the
+    //   24 significand bits), s ONE power of two per launch input (max |x| of the input tensors, published by their
+    //   producers / vam_absmax, lands in [2^14, 2^15): no overflow, 18 binades at full precision) and one per output channel
+    //   of the weights (made at pack time); three products hh + hl + lh on v_mfma_f32_32x32x16_f16; the scales are taken out
+    //   of the accumulators, exactly, before the epilogue.  LDS row: 8 chunks of 16 B = 128 B; logical chunk (p*4 + g) is
+    //   stored at chunk (p*4 + g) ^ ((row >> 1) & 7): rows alternate between the two halves of the 64 banks, so the 8 rows
+    //   of one parity among 16 consecutive ones must take 8 different chunks.
+    constexpr bool F16 = MODE == 3;
+    constexpr int NPL = F16 ? 2 : 3;                 // operand planes
+    constexpr int UPR = NPL * 4;                     // 16-byte chunks per LDS / packed-weight row
+    constexpr int RS = NPL * 16;
     constexpr int NBUF = SPEC ? 2 : ((BM + BN <= 128) ? 2 : 1);   // LDS buffers: 1.5x the bytes of fp32 rows, so wide tiles single-buffer (wave-specialised blocks always double-buffer)
-    constexpr int NBC = (BN * 12 + NT - 1) / NT;     // 16-byte weight chunks per thread and K chunk
+    constexpr int NBC = (BN * UPR + NT - 1) / NT;    // 16-byte weight chunks per thread and K chunk
     float* sA1 = smem;                               // [NBUF][BM][RS]
     float* sB1 = smem + NBUF * BM * RS;              // [NBUF][BN][RS]
     unsigned b_goff[NBC];
@@ -429,12 +444,27 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
     for (int j = 0; j < NBC; ++j) {
       const int idx = tid + j * NT;
-      const int row = idx / 12, c = idx - row * 12;
-      const bool in_tile = idx < BN * 12;
-      b_goff[j] = (in_tile && n0 + row < u_Npad) ? (unsigned)((n0 + row) * 192 + c * 16) : 0x80000000u;
-      b_loff[j] = in_tile ? row * RS + ((c & ~3) | ((c & 3) ^ ((row >> 2) & 3))) * 4 : -1;
+      const int row = idx / UPR, c = idx - row * UPR;
+      const bool in_tile = idx < BN * UPR;
+      b_goff[j] = (in_tile && n0 + row < u_Npad) ? (unsigned)((n0 + row) * (UPR * 16) + c * 16) : 0x80000000u;
+      b_loff[j] = in_tile ? row * RS + (F16 ? (c ^ ((row >> 1) & 7)) : ((c & ~3) | ((c & 3) ^ ((row >> 2) & 3)))) * 4 : -1;
     }
     const int u_Cin = __builtin_amdgcn_readfirstlane(P.Cin);
+    // MODE 3: the launch input's power-of-two scale from the published max |x| (of x^2 for GDN's pooled squares)
+    float a_scale = 1.f, a_unscale = 1.f;
+    if constexpr (F16) {
+      int mb = 0;                                    // non-negative floats: integer order = float order
+#pragma unroll
+      for (int k = 0; k < VAM_MAX_SEG; ++k)
+        if (P.in_amax[k]) mb = max(mb, *P.in_amax[k]);
+      float m = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(mb));
+      if (sq) m = m * m;
+      const int e = (int)((__float_as_uint(m) >> 23) & 0xFFu) - 127;             // floor(log2 m) of a normal m
+      int sh = (m > 0.f && e > -127 && e < 128) ? 14 - e : 0;
+      sh = sh > 126 ? 126 : (sh < -126 ? -126 : sh);
+      a_scale = __uint_as_float((unsigned)(sh + 127) << 23);
+      a_unscale = __uint_as_float((unsigned)(127 - sh) << 23);
+    }
     // register stages: chunk c lives in stage c & 1 between its global loads and its LDS store.  Double-buffered
     // (small) tiles use both stages, so a load has TWO compute phases to land — their phases are only 12-24 MFMAs long;
     // single-buffered (wide) tiles use stage 0 only.
@@ -477,7 +507,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       }
       // weights: [tap][32-channel chunk][Npad][12 chunks of 8 bf16] = 192 B per (n, chunk), pre-split at pack time
       // (dual: [tap pair][Npad][...], the pair's two 16-channel halves side by side)
-      const unsigned wbase = (unsigned)((dual ? (c_tap >> 1) : (c_tap * u_Kc + c_kc)) * u_Npad) * 192u;
+      const unsigned wbase = (unsigned)((dual ? (c_tap >> 1) : (c_tap * u_Kc + c_kc)) * u_Npad) * (unsigned)(UPR * 16);
 #pragma unroll
       for (int j = 0; j < NBC; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(b_goff[j] + wbase), 0, 0);
       // canonical K order: 32-channel group OUTER, tap INNER
@@ -496,6 +526,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     };
     static_assert(RPP % 16 == 0, "the swizzle of a thread's rows must not depend on the pass");
     const int st1_col = (((ld_col >> 3) ^ ((ld_row >> 2) & 3)) << 2);
+    const int st3_col[2] = {((((ld_col >> 3)) ^ ((ld_row >> 1) & 7)) << 2), (((4 + (ld_col >> 3)) ^ ((ld_row >> 1) & 7)) << 2)};   // MODE 3
     auto sstore = [&](int buf, const u32x4 (&ra)[NA][NAR], const u32x4 (&rb)[NBC]) {
       float* a = sA1 + buf * BM * RS;
       float* b = sB1 + buf * BN * RS;
@@ -514,6 +545,25 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
           if (sq) {                                  // GDN pools x^2 (block-uniform branch)
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = x[e] * x[e];
+          }
+          if constexpr (F16) {
+            // x 2^s = h + l: h nearest fp16, the remainder (exact in fp32) rounded to fp16 once more
+            unsigned hw2[4], lw2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x0 = x[2 * q] * a_scale, x1 = x[2 * q + 1] * a_scale;
+              const f16x2 h = {(_Float16)x0, (_Float16)x1};
+              const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+              hw2[q] = __builtin_bit_cast(unsigned, h);
+              lw2[q] = __builtin_bit_cast(unsigned, l);
+            }
+            float* drow = a + (ld_row + i * RPP) * RS;
+            u32x4 t;
+            t.x = hw2[0]; t.y = hw2[1]; t.z = hw2[2]; t.w = hw2[3];
+            *reinterpret_cast<u32x4*>(drow + st3_col[0]) = t;
+            t.x = lw2[0]; t.y = lw2[1]; t.z = lw2[2]; t.w = lw2[3];
+            *reinterpret_cast<u32x4*>(drow + st3_col[1]) = t;
+            continue;
           }
           // exact 3-way split by truncation: hi = top 16 bits of x, mid = top 16 bits of (x - hi), lo = x - hi - mid
           // (at most 8 significant bits are left, so its top 16 bits hold it exactly); two AND + two SUB per element
@@ -551,9 +601,35 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const int b_row1 = (wn * TN * 32 + l31) * RS;
     const int rsw = (l31 >> 2) & 3;                  // rows of a wave's 32-row groups differ by multiples of 32
     const int rd1[2] = {((lh ^ rsw) << 2), (((2 + lh) ^ rsw) << 2)};
+    const int rsw3 = (l31 >> 1) & 7;
+    const int rd3[2][2] = {{((lh ^ rsw3) << 2), (((4 + lh) ^ rsw3) << 2)}, {(((2 + lh) ^ rsw3) << 2), (((6 + lh) ^ rsw3) << 2)}};   // MODE 3: [k-step][plane]
     auto compute = [&](int buf) {
       const float* a = sA1 + buf * BM * RS + a_row1;
       const float* b = sB1 + buf * BN * RS + b_row1;
+      if constexpr (F16) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *reinterpret_cast<const f16x8*>(a + i * 32 * RS + rd3[ks][pl]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(b + j * 32 * RS + rd3[ks][pl]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              // fixed order, smallest terms first: (h,l) (l,h) (h,h)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+        }
+        return;
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 fa[TM][3], fb[TN][3];
@@ -580,6 +656,22 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         // seven column groups per wave: 112 accumulator + 96 fragment registers; keep hipcc from hoisting the next
         // sub-step's 96 fragment registers above this one's MFMAs (39 spilled registers otherwise)
         if constexpr (TN >= 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // MODE 3: take the two scales out of the accumulators (powers of two: exact).  The per-channel factors 2^-s_n sit
+    // behind the packed weights ([taps][Kc][Npad] rows of 128 B, then Npad floats).
+    auto unscale = [&]() {
+      if constexpr (F16) {
+        const float* wsc = P.wpack + (size_t)n_taps * u_Kc * u_Npad * 32;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 32 + l31;
+          const float f = (n < u_Npad ? wsc[n] : 0.f) * a_unscale;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+        }
       }
     };
     if constexpr (SPEC) {
@@ -620,6 +712,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
           compute(1);
           __syncthreads();
         }
+        unscale();
         // the whole C tile goes to LDS (it fits in the pipeline buffers, which every wave has left behind the last
         // barrier); C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (!direct_out) {
@@ -658,6 +751,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         compute(0);
         __syncthreads();
       }
+      unscale();
     } else {
       // single LDS buffer (wide tiles): registers hold chunk ch+1 while chunk ch is computed
       gload(ra0, rb0);
@@ -668,6 +762,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         compute(0);
         __syncthreads();
       }
+      unscale();
     }
   } else {
     // =============================================================== MODE 2: bf16 storage (BASELINE configs[2] "bf16")
@@ -853,6 +948,21 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     sPix[2 * slot] = pix;
     sPix[2 * slot + 1] = ob;
   };
+  // max |stored value| of this thread, folded into P.out_amax at the end (the consumer of this tensor may run in MODE 3)
+  float omax = 0.f;
+  const bool pub = P.out_amax != nullptr;
+  auto publish = [&]() {
+    if (pub) {
+      float m = omax;
+#pragma unroll
+      for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      // |x| >= 0: integer order = float order.  Thousands of waves fold into one cell: look first (a relaxed atomic load is
+      // served by L2, where the atomics land) and skip the read-modify-write unless this wave raises the maximum —
+      // same-address atomics serialise (measured: 49k of them cost 0.7 ms of a 0.6 ms launch)
+      if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_int(m) > __hip_atomic_load(P.out_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(P.out_amax, __float_as_int(m));
+    }
+  };
   // four consecutive channels (c4..c4+3) of tile row `row`, held in LDS row `srow`
   auto emit = [&](int srow, int row, int c4) {
     const int p = m0 + row;
@@ -891,6 +1001,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         const float4 t4 = ld_aux(P.post2, opix * P.ld_post2 + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
+      if (pub) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
       if (out_p3) {
         // bf16x3 planes for the consuming convolution: [pixel][8-channel group][plane][8 bf16]; this lane owns
         // channels cch..cch+3 = 8 bytes of each plane
@@ -932,6 +1043,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
         if (P.post) x = x + P.post[opix * P.ld_post + cch];
         if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
+        if (pub) omax = fmaxf(omax, fabsf(x));
         if (nchw) P.out[((size_t)ob * Cc + cch) * HfWf + (opix - (size_t)ob * HfWf)] = x;
         else P.out[opix * P.ldo + cch] = x;
       }
@@ -1053,11 +1165,17 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
             for (int r = 0; r < 16; ++r) v[r] += t[r];
           }
           const unsigned c4o = (poff * u_ldo + cch) << 2;
+          if (pub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (full_rows || pix4[r] != 0xFFFFFFFFu) omax = fmaxf(omax, fabsf(v[r]));
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
         }
       }
     }
+    publish();
     return;
   }
   if constexpr (SPEC) {
@@ -1086,6 +1204,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
       }
     }
   }
+  publish();
 }
 
 // ---------------------------------------------------------------- weight packing
@@ -1177,6 +1296,81 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   dst[row + (2 * 4 + g) * 8 + e] = (unsigned short)(lb >> 16);
 }
 
+// fp16x2 (MODE 3): per output channel n the power of two 2^s_n that maps max |w[n, :]| into [2^14, 2^15); out[n] = 2^-s_n
+// (1 for an all-zero channel).  One block per channel.
+__global__ void wscale_f16x2_kernel(const float* __restrict__ src, float* __restrict__ out, int mode, int phase, int kh, int kw,
+                                    int cin, int n, int npad) {
+  const int nn = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < kh * kw * cin; i += blockDim.x) {
+    const int tap = i / cin, cc = i - tap * cin;
+    m = fmaxf(m, fabsf(pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, tap / kw, tap % kw)));
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    m = red[0];
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFFu) - 127;
+    int sh = (m > 0.f && e > -127 && e < 128) ? 14 - e : 0;
+    sh = sh > 126 ? 126 : (sh < -126 ? -126 : sh);
+    out[nn] = __uint_as_float((unsigned)(127 - sh) << 23);
+  }
+  (void)npad;
+}
+
+// fp16x2 layout: [tap][32-channel chunk][Npad][8 chunks][8 fp16]; chunk (p*4 + g) holds plane p (h / l) of channels
+// 8g..8g+7; w 2^s_n = h + l up to 2^-22 |w|.  (dual: as in the bf16x3 layout)
+__global__ void pack_weights_f16x2_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, const float* __restrict__ wsc,
+                                          int mode, int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total, int dual) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  int kk = (int)(d % 32);
+  long r = d / 32;
+  int nn = (int)(r % npad);
+  r /= npad;
+  int c_chunk = (int)(r % kc32);
+  int tap = (int)(r / kc32);
+  int cc = c_chunk * 32 + kk;
+  if (dual) {
+    tap = 2 * tap + (kk >> 4);
+    cc = kk & 15;
+  }
+  int ty = tap / kw, tx = tap % kw;
+  const float v = (tap < kh * kw) ? pack_value(src, mode, phase, kh, kw, cin, n, nn, cc, ty, tx) : 0.f;
+  const float vs = v / wsc[nn];                      // 2^-s_n is a power of two: the division is exact
+  const _Float16 h = (_Float16)vs;
+  const _Float16 l = (_Float16)(vs - (float)h);
+  const size_t row = (size_t)(d / 32) * 64;          // 64 fp16 = 128 B per (chunk, n) row
+  const int g = kk >> 3, e = kk & 7;
+  dst[row + (0 * 4 + g) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+  dst[row + (1 * 4 + g) * 8 + e] = __builtin_bit_cast(unsigned short, l);
+}
+
+// max |x| over an NHWC window, folded into *cell (the float's bits; integer atomicMax).  float4 loads, grid-stride.
+struct AbsmaxArgs { const float* ptr[VAM_MAX_SEG]; int C[VAM_MAX_SEG]; int ld[VAM_MAX_SEG]; int n_seg; long n_pix; int* cell; };
+__global__ __launch_bounds__(256) void absmax_kernel(const AbsmaxArgs a) {
+  float m = 0.f;
+  for (int s = 0; s < a.n_seg; ++s) {
+    const int c4 = a.C[s] >> 2;
+    const long total = a.n_pix * c4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long pix = i / c4;
+      const int c = (int)(i - pix * c4);
+      const float4 v = *reinterpret_cast<const float4*>(a.ptr[s] + pix * a.ld[s] + 4 * c);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_int(m) > __hip_atomic_load(a.cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(a.cell, __float_as_int(m));
+}
+
 // bf16 storage mode: [tap][32-channel chunk][Npad][32 bf16] = 64 B per row, each weight rounded to nearest-even bf16
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
                                          int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total) {
@@ -1225,12 +1419,12 @@ static inline bool dual_tap(int cin, int taps) { return cin == 16 && taps > 1; }
 
 static inline int bk_for(int cin) { return (cin % 32 == 0) ? 32 : 16; }   // kernel K step (packing is always 16-granular)
 
-static int g_mode = -1;              // 0 = fp32 MFMA, 1 = bf16x3 MFMA; -1 = not chosen yet (VAMPIC_CONV, default bf16x3)
+static int g_mode = -1;              // 0 = fp32 MFMA, 1 = bf16x3 MFMA, 3 = fp16x2 MFMA (opt-in); -1 = not chosen yet (VAMPIC_CONV, default bf16x3)
 
 static int conv_mode() {
   if (g_mode < 0) {
     const char* e = getenv("VAMPIC_CONV");
-    g_mode = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+    g_mode = (e && (e[0] == 'f' || e[0] == 'F')) ? ((e[1] == '1') ? 3 : 0) : 1;      // "f32" -> 0, "f16x2" -> 3
   }
   return g_mode;
 }
@@ -1238,7 +1432,7 @@ static int conv_mode() {
 template <int BM, int BN, int BK, int WGM, int WGN, int MODE, int AIN = 0, int SPEC = 0>
 static int launch_cfg(const GroupArgs& ga, int total_tiles, hipStream_t s) {
   constexpr size_t pipe = MODE == 2 ? (size_t)2 * (BM + BN) * 16 * sizeof(float)
-                          : MODE ? (size_t)((SPEC || BM + BN <= 128) ? 2 : 1) * (BM + BN) * 48 * sizeof(float)
+                          : MODE ? (size_t)((SPEC || BM + BN <= 128) ? 2 : 1) * (BM + BN) * (MODE == 3 ? 32 : 48) * sizeof(float)
                                  : (size_t)2 * (BM + BN) * BK * sizeof(float);
   constexpr int crows = SPEC ? BM : WGM * 32;              // rows of C staged through LDS at a time
   constexpr size_t ctile = (size_t)crows * (BN + 4) * sizeof(float) + (size_t)crows * 2 * sizeof(int);
@@ -1282,8 +1476,8 @@ int vam_conv_force_epilogue(int staged) {
 }
 
 int vam_conv_set_mode(int mode) {
-  if (mode != 0 && mode != 1) {
-    set_error("vam_conv_set_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  if (mode != 0 && mode != 1 && mode != 3) {
+    set_error("vam_conv_set_mode: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA, 3 = fp16x2 MFMA)", mode);
     return VAM_EINVAL;
   }
   g_mode = mode;
@@ -1295,6 +1489,7 @@ int vam_conv_get_mode(void) { return conv_mode(); }
 size_t vam_conv_wpack_floats(int kh, int kw, int cin, int n) {
   int npad = (n + 31) / 32 * 32;
   if (conv_mode() == 1) return (size_t)kh * kw * ((cin + 31) / 32) * npad * 48;   // 96 bf16 per (n, 32-channel chunk)
+  if (conv_mode() == 3) return (size_t)kh * kw * ((cin + 31) / 32) * npad * 32 + npad;   // 64 fp16 per row, then 2^-s_n per channel
   int bk = PK;
   int kc = (cin + bk - 1) / bk;
   return (size_t)kh * kw * kc * npad * bk;
@@ -1310,6 +1505,16 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase, int
     VAM_REQUIRE(phase < 4 && kh == ((phase >> 1) ? 2 : 3) && kw == ((phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", phase);
   if (mode == VAM_PACK_GDN || mode == VAM_PACK_GDN_T) VAM_REQUIRE(kh == 1 && kw == 1 && cin == n, "GDN pack is 1x1 and square");
   int npad = (n + 31) / 32 * 32;
+  if (conv_mode() == 3) {
+    const int kc32 = (cin + 31) / 32;
+    const int dual = dual_tap(cin, kh * kw) ? 1 : 0;
+    const long total1 = dual ? (long)((kh * kw + 1) / 2) * npad * 32 : (long)kh * kw * kc32 * npad * 32;
+    float* wsc = dst + (size_t)kh * kw * kc32 * npad * 32;
+    hipLaunchKernelGGL(wscale_f16x2_kernel, dim3(npad), dim3(256), 0, (hipStream_t)stream, src, wsc, mode, phase, kh, kw, cin, n, npad);
+    hipLaunchKernelGGL(pack_weights_f16x2_kernel, dim3(cdiv(total1, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<unsigned short*>(dst), wsc, mode, phase, kh, kw, cin, n, npad, kc32, total1, dual);
+    return check_launch("pack_weights_f16x2_kernel");
+  }
   if (conv_mode() == 1) {
     const int kc32 = (cin + 31) / 32;
     const int dual = dual_tap(cin, kh * kw) ? 1 : 0;       // 16-channel inputs: two taps per 32-channel chunk (kernel: VAM_CONVI_DUAL)
@@ -1386,6 +1591,9 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     if (c_aux16) VAM_REQUIRE(!(c.flags & (VAM_CONV_OUT_NCHW)) && (!(c.flags & VAM_CONV_PS2) || (c.Cq % 4) == 0), "conv[%d]: bf16 epilogue operands need the vector epilogue", i);
     if (i == 0) in_p3 = p3_in;
     VAM_REQUIRE(p3_in == in_p3, "conv group mixes fp32 and bf16x3-plane inputs");
+    if (conv_mode() == 3 && !c_w16)
+      for (int sg = 0; sg < c.n_seg; ++sg)
+        VAM_REQUIRE(c.in_amax[sg] != nullptr, "conv[%d]: the fp16x2 mode needs in_amax[%d] (max |x| of that input segment: vam_absmax, or its producer's out_amax)", i, sg);
     if (p3_in || p3_out) VAM_REQUIRE(conv_mode() == 1, "conv[%d]: bf16x3-plane tensors need the split-operand mode", i);
     if (p3_in) VAM_REQUIRE(!(c.flags & VAM_CONV_SQUARE_IN), "conv[%d]: SQUARE_IN needs fp32 input", i);
     if (p3_out) VAM_REQUIRE(!(c.flags & (VAM_CONV_PS2 | VAM_CONV_OUT_NCHW)) && c.N % 8 == 0 && c.ldo * 8 >= c.N, "conv[%d]: bf16x3-plane output needs plain NHWC placement, N %% 8 == 0 and ldo (groups) >= N/8", i);
@@ -1411,7 +1619,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
         p.seg_end[s] = 1 << 30;
       }
     }
-    const int mode1 = conv_mode() == 1 || c_w16;
+    const int mode1 = conv_mode() == 1 || conv_mode() == 3 || c_w16;
     int pbk = mode1 ? 32 : bk_for(cin);
     VAM_REQUIRE(cin % 16 == 0, "conv[%d]: Cin %d not a multiple of 16", i, cin);
     for (int sgi = 0; sgi < c.n_seg; ++sgi)
@@ -1458,7 +1666,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     // 16-channel multi-tap problems: vam_pack_conv_weights lays the weights out two taps per 32-channel chunk in the
     // split-operand mode (dual_tap), and ONLY the dual-tap indexing reads that layout — so every such problem must be one
     // the dual path takes (one fp32 segment); anything else would read dual-packed weights with plain indexing
-    if (conv_mode() == 1 && !c_w16 && dual_tap(cin, c.kh * c.kw)) {
+    if ((conv_mode() == 1 || conv_mode() == 3) && !c_w16 && dual_tap(cin, c.kh * c.kw)) {
       VAM_REQUIRE(!p3_in && c.n_seg == 1, "conv[%d]: a 16-channel multi-tap problem takes one fp32 input segment (its weights are "
                   "packed two taps per chunk)", i);
       p.flags |= VAM_CONVI_DUAL;
@@ -1480,6 +1688,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;
     p.post2 = c.post2.ptr; p.ld_post2 = c.post2.ld;
+    for (int sg = 0; sg < VAM_MAX_SEG; ++sg) p.in_amax[sg] = sg < c.n_seg ? c.in_amax[sg] : nullptr;
+    p.out_amax = c.out_amax;
     if (P > max_p) max_p = P;
     if (c.N > max_n) max_n = c.N;
     flops += 2.0 * (double)P * c.N * cin * c.kh * c.kw;
@@ -1503,7 +1713,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
   // plus the wave-specialised 128x224 tile (below)
   static const Cand cands1[10] = {{128, 192, 1.0}, {128, 128, 0.974}, {128, 96, 1.021}, {128, 64, 1.035}, {128, 32, 1.35},
                                   {64, 192, 1.05}, {64, 128, 1.019}, {64, 64, 1.05}, {64, 32, 1.363}, {128, 224, 1.0}};
-  const bool m1 = conv_mode() == 1 || w16;
+  const bool m1 = conv_mode() == 1 || conv_mode() == 3 || w16;
   const Cand* cand = m1 ? cands1 : cands;
   const int n_cand = m1 ? 10 : 14;
   // deep-K launches of the split-operand mode may use the wave-specialised 128x224 tile (4x1 consumer waves of 32 x 224:
@@ -1518,7 +1728,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     const char* e = getenv("VAMPIC_SPEC");
     spec_env0 = e ? (e[0] == '1' ? 1 : 0) : -1;
   }
-  const bool wide224_ok = conv_mode() == 1 && !w16 && spec_env0 != 0 && min_chunks32 >= 16;
+  const bool wide224_ok = (conv_mode() == 1 || conv_mode() == 3) && !w16 && spec_env0 != 0 && min_chunks32 >= 16;
   const double b512 = m1 ? 1.018 : 1.04, b256 = m1 ? 1.097 : 1.10, k96 = m1 ? 1.084 : 1.1;
   int bm = 128, best_bn = 128;
   double best_score = -1.0;
@@ -1552,7 +1762,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     bk = 16;
     for (int i = 0; i < nprob; ++i) ga.p[i].Kc = ga.p[i].Kc16;
   }
-  if (conv_mode() == 1 || w16) {
+  if (conv_mode() == 1 || conv_mode() == 3 || w16) {
     // bf16x3 path: K step is always 32; configurations whose operand fragments would not fit the register file
     // (seven 32-column groups per wave) fall back to their two-tile neighbours
     bk = 32;
@@ -1581,7 +1791,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     set_error("vam_conv_group: no bf16 kernel configuration for BM=%d BN=%d", bm, best_bn);
     return VAM_EINVAL;
   }
-  if (conv_mode() == 1) {
+  if (conv_mode() == 1 || conv_mode() == 3) {
+    const bool f16 = conv_mode() == 3;
     // Wave-specialised blocks where they measured faster (interleaved A/B on one box, scratch/ab_spec.sh): the small
     // tiles of the slice chain (64x32 / 64x64 / 64x128: +12...+32 %) and the large tiles of deep-K layers (128x128,
     // 128x192: +3...+7 %); short-K layers (1x1, the 16-channel first layer) and the 4x1-wave 128x96 tile lose 15-30 %
@@ -1602,6 +1813,8 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     const bool spec = (bm == 128 && best_bn == 224) || (spec_env >= 0 ? (spec_env == 1) : (spec_tile && min_chunks >= 16));
 #define VAM_CFG1(BM_, BN_, WGM_, WGN_) \
     if (bm == BM_ && best_bn == BN_) {                                                                      \
+      if (f16) return spec ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 3, 0, 1>(ga, total, s)                    \
+                           : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 3, 0, 0>(ga, total, s);                   \
       if (spec) return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 1>(ga, total, s)                  \
                              : launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 0, 1>(ga, total, s);                 \
       return in_p3 ? launch_cfg<BM_, BN_, 32, WGM_, WGN_, 1, 1, 0>(ga, total, s)                            \
@@ -1610,6 +1823,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     VAM_CFG1(128, 32, 4, 1) VAM_CFG1(128, 64, 2, 2) VAM_CFG1(128, 96, 4, 1) VAM_CFG1(128, 128, 2, 2) VAM_CFG1(128, 192, 2, 2)
     VAM_CFG1(64, 32, 2, 1) VAM_CFG1(64, 64, 2, 2) VAM_CFG1(64, 128, 2, 2) VAM_CFG1(64, 192, 2, 2)
 #undef VAM_CFG1
+    if (bm == 128 && best_bn == 224 && f16) return launch_cfg<128, 224, 32, 4, 1, 3, 0, 1>(ga, total, s);
     if (bm == 128 && best_bn == 224)
       return in_p3 ? launch_cfg<128, 224, 32, 4, 1, 1, 1, 1>(ga, total, s) : launch_cfg<128, 224, 32, 4, 1, 1, 0, 1>(ga, total, s);
     set_error("vam_conv_group: no bf16x3 kernel configuration for BM=%d BN=%d", bm, best_bn);
@@ -1625,6 +1839,23 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
 #undef VAM_CFG
   set_error("vam_conv_group: no kernel configuration for BM=%d BN=%d", bm, best_bn);
   return VAM_EINVAL;
+}
+
+int vam_absmax(const vam_seg* segs, int n_seg, long n_pix, int32_t* cell, void* stream) {
+  VAM_REQUIRE(segs && n_seg >= 1 && n_seg <= VAM_MAX_SEG && n_pix > 0 && cell, "vam_absmax: bad arguments");
+  AbsmaxArgs a;
+  double work = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    VAM_REQUIRE(segs[s].ptr && segs[s].C > 0 && segs[s].C % 4 == 0 && segs[s].ld % 4 == 0 && (((uintptr_t)segs[s].ptr) & 15) == 0,
+                "vam_absmax: segment %d needs C, ld multiples of 4 and a 16-byte aligned pointer", s);
+    a.ptr[s] = segs[s].ptr; a.C[s] = segs[s].C; a.ld[s] = segs[s].ld;
+    work += (double)n_pix * segs[s].C / 4;
+  }
+  a.n_seg = n_seg; a.n_pix = n_pix; a.cell = cell;
+  long blocks = (long)(work / 256 / 8) + 1;            // ~8 float4 per thread
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("absmax_kernel");
 }
 
 }  // extern "C"

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence
 
+import ctypes as C
+import os
 import torch
 import torch.nn as nn
 
@@ -46,6 +48,17 @@ class Plan:
         # resolution — the sigma stacks, the mask, the likelihoods — stays fp32
         self.act16 = False
         self.act16_min_hw = 4096        # 64 x 64 positions per image ("bf16 activations on >= 64^2 feature maps")
+        # fp16x2 mode (opt-in, VAMPIC_CONV=f16x2): every conv launch needs an upper bound of max |x| of each input segment.
+        # One cell per plan buffer, written by the epilogues of the conv launches that fill the buffer (vam_conv.out_amax);
+        # inputs that something else wrote (or that the plan does not own) are reduced in front of the launch (vam_absmax).
+        # The pool is zeroed by the plan's first step, ahead of any branch.
+        self._amax_pool: Optional[torch.Tensor] = None
+        self._amax_next = 0
+        self._amax_bufs: List[list] = []      # [start, end, cell index, state]  state: 0 unwritten, 1 conv-written, 2 other
+        if ops.f16x2_mode():
+            self._amax_pool = torch.zeros(8192, dtype=torch.int32, device=self.device)
+            pool = self._amax_pool
+            self.call(lambda: ops.memset_zero(pool), "zero max cells")
 
     # ---- buffers
     def buf(self, B, H, W, C, zero=False) -> View:
@@ -55,13 +68,82 @@ class Plan:
             return v16
         v = ops.new_view(B, H, W, C, self.device, zero=zero)
         self.keep.append(v.buf)
+        self._amax_register(v)
         return v
 
     def buf32(self, B, H, W, C) -> View:
         """fp32 whatever the storage mode (tensors the window-attention kernel reads / writes)."""
         v = ops.new_view(B, H, W, C, self.device)
         self.keep.append(v.buf)
+        self._amax_register(v)
         return v
+
+    # ---- fp16x2 mode: max-|x| cells
+    def _amax_cell(self) -> int:
+        i = self._amax_next
+        assert i < self._amax_pool.numel(), "max-cell pool exhausted"
+        self._amax_next += 1
+        return i
+
+    def _amax_register(self, v: View):
+        if self._amax_pool is not None:
+            p0 = v.buf.data_ptr()
+            self._amax_bufs.append([p0, p0 + v.buf.numel() * 4, self._amax_cell(), 0])
+
+    def _amax_find(self, ptr: int):
+        for b in self._amax_bufs:
+            if b[0] <= ptr < b[1]:
+                return b
+        return None
+
+    def written_by_other(self, *views):
+        """Tell the plan that something other than a conv launch writes these tensors (their max cells are not trusted)."""
+        if self._amax_pool is not None:
+            for v in views:
+                b = self._amax_find(v.ptr)
+                if b is not None:
+                    b[3] = 2
+
+    def _amax_cells(self, chunk):
+        lib = L.load()
+        base = self._amax_pool.data_ptr()
+        fills = []
+        check = os.environ.get("VAMPIC_AMAX_CHECK", "0") == "1"
+        track = os.environ.get("VAMPIC_AMAX_TRACK", "1") != "0"     # 0: reduce every input in front of its launch (exact max; measurement aid)
+        for c in chunk:
+            if c.flags & (L.CONV_W_BF16 | L.CONV_IN_BF3):
+                continue
+            npix = c.B * c.H * c.W
+            for k in range(c.n_seg):
+                b = self._amax_find(c.seg[k].ptr)
+                if b is not None and b[3] == 1 and track:
+                    c.in_amax[k] = base + 4 * b[2]
+                    if check:
+                        fills.append((c, k, base + 4 * self._amax_cell(), base + 4 * b[2]))
+                else:
+                    cell = base + 4 * self._amax_cell()
+                    c.in_amax[k] = cell
+                    fills.append((c, k, cell, None))
+            if not (c.flags & L.CONV_OUT_NCHW):
+                b = self._amax_find(c.out)
+                if b is not None and b[3] != 2:
+                    c.out_amax = base + 4 * b[2]
+                    b[3] = 1
+        if fills:
+            self.keep.append(chunk)
+
+            def fill():
+                s = ops.stream_ptr()
+                for c, k, cell, tracked in fills:
+                    L.check(lib.vam_absmax(C.byref(c.seg[k]), 1, c.B * c.H * c.W, cell, s), "vam_absmax")
+                    if tracked is not None:      # VAMPIC_AMAX_CHECK=1: the tracked cell must bound what the tensor holds now
+                        torch.cuda.current_stream().synchronize()
+                        off_t, off_c = (tracked - base) // 4, (cell - base) // 4
+                        t, m = int(self._amax_pool[off_t]), int(self._amax_pool[off_c])
+                        if t < m:
+                            raise RuntimeError(f"fp16x2: tracked max cell {t:#x} below the tensor's max {m:#x} "
+                                               f"(segment {k} of a [{c.N} ch, k{c.kh}] problem): an untracked writer")
+            self.call(fill, "absmax")
 
     def pk(self, m, ins, out, aux=()):
         """Packed weights of ``m`` for a problem reading ``ins`` and writing ``out``: bf16 weights as soon as one of
@@ -80,6 +162,8 @@ class Plan:
         lib = L.load()
         for i in range(0, len(problems), L.VAM_MAX_GROUP):
             chunk = list(problems[i:i + L.VAM_MAX_GROUP])
+            if self._amax_pool is not None:
+                self._amax_cells(chunk)
             arr = (L.VamConv * len(chunk))(*chunk)
             n = len(chunk)
             self.keep.append(arr)

@@ -286,6 +286,8 @@ class VarianceMaskingPIC(CompressionModel):
         if getattr(self, "storage", "fp32") == "bf16" and (train or symbols):
             raise NotImplementedError("bf16 storage is an inference configuration (forward_single_quality): training and "
                                       "the bitstream path run in fp32")
+        if ops.f16x2_mode() and (train or symbols):
+            raise NotImplementedError("the fp16x2 arithmetic (VAMPIC_CONV=f16x2) is an evaluation-forward configuration: its results depend, in the last bits, on the power-of-two scale of each launch (batch composition, plan structure), so the bitstream path (encoder and decoder must agree bit for bit) and training run in the default bf16x3 arithmetic")
         p = self._plans.get(key)
         if p is not None and rem_idx is not None and not train and p.rem_sig != _version_sig(self.post_latent[rem_idx]):
             p = None                # the REM was fine-tuned since this plan packed its weights
@@ -397,6 +399,8 @@ class VarianceMaskingPIC(CompressionModel):
         `refine_gs_ga` as a subset): full_train.FullTrainPlan, autograd-connected through :class:`_FullTrainFn`.
         ``single`` = False: ``forward(x, [0, q])`` (pic.py:301-491); True: ``forward_single_quality(x, q)`` (:497-666)."""
         from .full_train import FullTrainPlan
+        if ops.f16x2_mode():
+            raise NotImplementedError("the fp16x2 arithmetic (VAMPIC_CONV=f16x2) is an evaluation-forward configuration: its results depend, in the last bits, on the power-of-two scale of each launch (batch composition, plan structure), so the bitstream path (encoder and decoder must agree bit for bit) and training run in the default bf16x3 arithmetic")
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in ("point-based-std", "two-levels"):
             raise NotImplementedError()
@@ -504,6 +508,8 @@ class VarianceMaskingPIC(CompressionModel):
         if dp is not None and dp.wsig != wsig:
             dp = None               # a weight was edited in place since the plan packed it
         if dp is None:
+            if ops.f16x2_mode():
+                raise NotImplementedError("the fp16x2 arithmetic (VAMPIC_CONV=f16x2) is an evaluation-forward configuration: its results depend, in the last bits, on the power-of-two scale of each launch (batch composition, plan structure), so the bitstream path (encoder and decoder must agree bit for bit) and training run in the default bf16x3 arithmetic")
             dp = _DecPlan(self, B, hz, wz, base_only, rem_idx, dev)
             dp.wsig = wsig
             dp.rem_sig = _version_sig(self.post_latent[rem_idx]) if rem_idx is not None else None

@@ -126,6 +126,37 @@ def split_mode() -> bool:
     return L.load().vam_conv_get_mode() == 1
 
 
+def f16x2_mode() -> bool:
+    """True when the convolution kernel runs on fp16x2 operands (opt-in: VAMPIC_CONV=f16x2 / vam_conv_set_mode(3))."""
+    return L.load().vam_conv_get_mode() == 3
+
+
+def amax_prepare(chunk: Sequence["L.VamConv"]):
+    """fp16x2 mode, eager launches (``conv_group``): give every input segment of every problem of one grouped launch a
+    max-|x| cell and return (cells, fn) where ``fn()`` zeroes the cells and reduces each segment into its cell on the
+    current stream.  Plans avoid the re-read where the producer was a convolution (engine.Plan: ``out_amax`` cells)."""
+    lib = L.load()
+    cells = torch.zeros(len(chunk) * L.VAM_MAX_SEG, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    base = cells.data_ptr()
+    todo = []
+    for i, c in enumerate(chunk):
+        if c.flags & (L.CONV_W_BF16 | L.CONV_IN_BF3):
+            continue
+        for k in range(c.n_seg):
+            cell = base + 4 * (i * L.VAM_MAX_SEG + k)
+            c.in_amax[k] = cell
+            todo.append((c, k, cell))
+
+    def fill():
+        if not todo:
+            return
+        s = stream_ptr()
+        L.check(lib.vam_memset_zero(base, 4 * cells.numel(), s), "vam_memset_zero")
+        for c, k, cell in todo:
+            L.check(lib.vam_absmax(C.byref(c.seg[k]), 1, c.B * c.H * c.W, cell, s), "vam_absmax")
+    return cells, fill
+
+
 def new_view(B: int, H: int, W: int, C_: int, device="cuda", zero: bool = False) -> View:
     f = torch.zeros if zero else torch.empty
     return View(f((B, H, W, C_), dtype=torch.float32, device=device), 0, C_)
@@ -352,6 +383,9 @@ def conv_group(problems: Sequence[L.VamConv]):
     s = stream_ptr()
     for i in range(0, len(problems), L.VAM_MAX_GROUP):
         chunk = problems[i:i + L.VAM_MAX_GROUP]
+        if f16x2_mode():
+            cells, fill = amax_prepare(chunk)
+            fill()
         arr = (L.VamConv * len(chunk))(*chunk)
         L.check(lib.vam_conv_group(arr, len(chunk), s), "vam_conv_group")
 

@@ -110,6 +110,11 @@ typedef struct vam_conv {
   int32_t act;              /* enum vam_act                                           */
   int32_t flags;            /* enum vam_conv_flags                                    */
   vam_aux pre, mul, post, post2;
+  const int32_t* in_amax[VAM_MAX_SEG]; /* fp16x2 mode (vam_conv_set_mode(3)): per input segment a device cell holding the bits
+                               of an upper bound of max |x| of that segment (vam_absmax, or the out_amax cell of the launches
+                               that wrote it); the launch scales by the largest.  Ignored in the other modes.            */
+  int32_t* out_amax;        /* any mode, optional: the epilogue folds max |stored value| into this device cell (integer
+                               atomicMax on the float's bits; zero the cell before the first producer of a step)     */
 } vam_conv;
 
 /* sizeof(vam_conv) as compiled into the library (binding layout guard). */
@@ -144,6 +149,9 @@ int vam_pack_conv_weights_bf16(const float* src, void* dst, int mode, int phase,
  * merged-deconv replication (4x). mode as above. */
 int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
 
+/* max |x| over up to VAM_MAX_SEG NHWC windows of n_pix pixels each, folded into *cell like vam_conv.out_amax. */
+int vam_absmax(const vam_seg* segs, int n_seg, long n_pix, int32_t* cell, void* stream);
+
 /* Launch up to VAM_MAX_GROUP independent problems as ONE grid (grouped launch:
  * e.g. the mean and scale stacks of one slice, or the four phases of a deconv). */
 #define VAM_MAX_GROUP 8
@@ -157,8 +165,11 @@ int vam_conv_force_tile(int bm, int bn, int bk);
 int vam_conv_force_epilogue(int staged);
 /* Arithmetic of the convolution kernel.  1 (default): every fp32 operand is split exactly into three bf16 terms and
  * the product is formed from six exact bf16 x bf16 partial products on the bf16 matrix pipe, fp32 accumulation
- * (error vs float64 no larger than the fp32 fma chain's); 0: fp32 operands on the fp32 matrix pipe.
- * The mode fixes the packed-weight layout: choose it (or the environment variable VAMPIC_CONV=f32|bf16x3) before
+ * (error vs float64 no larger than the fp32 fma chain's); 0: fp32 operands on the fp32 matrix pipe;
+ * 3 (opt-in, round 3 prototype): every fp32 operand scaled by a power of two (one per launch input, from vam_conv.in_amax;
+ * one per output channel of the weights, made at pack time) and split into two fp16 terms, three products on the fp16
+ * matrix pipe, fp32 accumulation — 22 of 24 significand bits per operand, below fp32 accumulation noise.
+ * The mode fixes the packed-weight layout: choose it (or the environment variable VAMPIC_CONV=f32|bf16x3|f16x2) before
  * the first vam_conv_wpack_floats / vam_pack_conv_weights call and do not change it while packed weights exist. */
 int vam_conv_set_mode(int mode);
 int vam_conv_get_mode(void);

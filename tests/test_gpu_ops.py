@@ -426,3 +426,55 @@ def test_entropy_bottleneck_aux_loss_and_gradient():
         l.backward()
         opt.step()
     assert float(eb.loss()) < before
+
+
+def test_epilogues_publish_the_output_maximum():
+    """``vam_conv.out_amax``: every epilogue path (direct from the accumulators, LDS-staged, wave-specialised blocks, the
+    scalar NCHW / PixelShuffle tail) folds max |stored value| into a device cell — the scale source of the fp16x2 mode's
+    consumers — and ``vam_absmax`` reduces a channel window of an NHWC tensor the same way."""
+    import ctypes
+    lib = L.load()
+    for cin, n, k, st, B, H, W, act in [(192, 192, 1, 1, 2, 32, 32, L.ACT_GELU),      # 128x64 one-role tile: direct epilogue
+                                        (192, 192, 3, 1, 2, 32, 32, L.ACT_NONE),      # wide tile, staged
+                                        (224, 176, 3, 1, 4, 16, 16, L.ACT_GELU),      # wave-specialised 64x64
+                                        (96, 44, 3, 2, 1, 24, 40, L.ACT_LEAKY)]:      # ragged N, stride 2
+        m = Ly.Conv2d(cin, n, k, st).cuda()
+        _fill(m, 90 + n)
+        x = ops.from_nchw(_rand((B, cin, H, W), 91).cuda())
+        wide = ops.new_view(B, H // st, W // st, n + 8, zero=True)                    # the output is a channel window
+        out = wide.window(4, n)
+        cell = torch.zeros(2, dtype=torch.int32, device="cuda")
+        c = ops.conv_problem(m.packed(), [x], out, act)
+        c.out_amax = cell.data_ptr()
+        ops.conv_group([c])
+        torch.cuda.synchronize()
+        want = wide.buf[..., 4:4 + n].abs().max()
+        assert cell[:1].view(torch.float32).item() == want.item(), (cin, n, k)
+        assert cell[1].item() == 0
+        seg = (L.VamSeg * 1)()
+        seg[0].ptr, seg[0].C, seg[0].ld = out.ptr, n, out.ld
+        L.check(lib.vam_absmax(seg, 1, out.n_pix, cell.data_ptr() + 4, ops.stream_ptr()), "vam_absmax")
+        torch.cuda.synchronize()
+        assert cell[1:].view(torch.float32).item() == want.item()
+
+
+def test_fp16x2_mode_in_a_child_process():
+    """VAMPIC_CONV=f16x2 (opt-in prototype): fp32 operands as two fp16 terms with power-of-two scales, three
+    MFMA products.  Like the fp32-pipe mode it fixes the packed-weight layout for the life of a process, so it runs in a
+    child: the convolution tests (F.conv2d tolerances, the float64 error bound, tiling invariance, direct vs staged
+    epilogue) and the model-level parity tests against the oracle must pass there unchanged."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VAMPIC_CONV="f16x2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "conv2d or deconv or gdn or tiling or float64 or rem_block or epilogue"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_model.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "single_quality_parity or flip_aware or graph_replay"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
