@@ -15,6 +15,8 @@
 namespace vam {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // dW[n][c_off + c][ty][tx] = sum_p dY[p][n] * X[pix(p) + (ty - pad, tx - pad)][c]      (stride 1)
 // grid = (taps * N/32 tiles * C/32 tiles * pixel splits [max over the group], problems).  8 waves split the pixels of the
@@ -26,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // order.  Deterministic either way: no float atomics.
 constexpr int WG_WAVES = 8, WG_BATCH = 16;   // MFMAs per batch; each covers 2 pixels
 
+
 struct WgradArgs {
   vam_wgrad p[VAM_MAX_WGRAD_GROUP];
 };
@@ -34,7 +37,13 @@ struct WgradArgs {
 // row of dY, one of X per pixel pair) and a [192->192 k5] layer reads its two tensors 25 x 6 times over (30 GB from L2 for
 // one launch, 41 TF/s); a 64x64 tile issues four MFMAs per four loads and halves that traffic.  Chosen per launch by
 // wgrad_tile(): 2x2 where both channel counts are multiples of 64, 3x1 for the 96-channel layers, 2x1 / 1x2 / 1x1 otherwise.
-template <int TN, int TC>
+// SPLIT (default; VAMPIC_WGRAD=f32 keeps the fp32-pipe loop): the same sum on the bf16 matrix pipe.  K of this GEMM is the
+// pixel axis and BOTH operands are activations, so both are split on the fly: a lane of v_mfma_f32_32x32x16_bf16 holds 8
+// consecutive pixels of one channel — 8 dword loads (each still a coalesced 128-byte row across the 32 lanes, the same number
+// of load instructions per pixel as the fp32 loop), split exactly into hi / mid / lo bf16 planes (truncation, as the
+// convolution kernel's), six products per 16 pixels and block instead of eight fp32 MFMAs of twice the length: 192 vs 512
+// matrix-pipe cycles.  Products are exact either way; the fp32 accumulation order differs, the result is as deterministic.
+template <int TN, int TC, int SPLIT>      // SPLIT: 0 = fp32 pipe, n > 0 = bf16 pipe with n 16-pixel steps per loop iteration (1 is used)
 __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs args) {
   __shared__ float red[WG_WAVES][32][33];
   __shared__ float redb[WG_WAVES][2][32];
@@ -80,6 +89,90 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
   float bsum[TN];
 #pragma unroll
   for (int u = 0; u < TN; ++u) bsum[u] = 0.f;
+  if constexpr (SPLIT) {
+    // exact hi / mid / lo planes of 8 values (truncation split), packed two bf16 per dword
+    auto split8 = [](const float (&f)[8], bf16x8 (&pl)[3]) {
+      unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hb[e] = __float_as_uint(f[e]);
+        const float r1 = f[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
+        mb[e] = __float_as_uint(r1);
+        lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e] & 0xFFFF0000u));
+      }
+      u32x4 h, m, l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
+      }
+      pl[0] = __builtin_bit_cast(bf16x8, h);
+      pl[1] = __builtin_bit_cast(bf16x8, m);
+      pl[2] = __builtin_bit_cast(bf16x8, l);
+    };
+    // 16-pixel MFMA steps per loop iteration, all their loads issued first.  Two (SPLIT = 2) measured no better over a
+    // first_train step: 88.2 vs 82.3 ms of weight gradients — the deep-pixel layers gain 5 %, the pixel-split ones (a few
+    // hundred pixels per wave) lose 30 %; choosing per launch landed in between (86.4 ms).  One it is.
+    constexpr int NH = SPLIT;
+    for (long pb = p_begin + (long)wid * (16 * NH); pb < p_end; pb += (long)WG_WAVES * 16 * NH) {
+      float af[NH][TN][8], bf[NH][TC][8];
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf) {
+        // this lane's 8 pixels of the step: pb + 16 hf + 8 lh + j; position of the first by division, the rest by carry
+        const long pf = pb + 16 * hf + 8 * lh;
+        int bi = (int)(pf / HW);
+        const int r0 = (int)(pf - (long)bi * HW);
+        int oy = r0 / W, ox = r0 - oy * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long p = pf + j;
+#pragma unroll
+          for (int u = 0; u < TN; ++u) af[hf][u][j] = 0.f;
+#pragma unroll
+          for (int v = 0; v < TC; ++v) bf[hf][v][j] = 0.f;
+          if (p < p_end) {
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+              if (n_ok[u]) af[hf][u][j] = dy[p * ld_dy + n0 + 32 * u + l31];
+            const int iy = oy * stride - pad_y + ty, ix = ox * stride - pad_x + tx;
+            if ((unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx) {
+              const float* xp = x + ((long)bi * HWx + (long)iy * Wx + ix) * ld_x + c0 + l31;
+#pragma unroll
+              for (int v = 0; v < TC; ++v)
+                if (c_ok[v]) bf[hf][v][j] = xp[32 * v];
+            }
+          }
+          ++ox;
+          if (ox == W) { ox = 0; ++oy; if (oy == H) { oy = 0; ++bi; } }
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < NH; ++hf) {
+        bf16x8 fa[TN][3], fb[TC][3];
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+          split8(af[hf][u], fa[u]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[u] += af[hf][u][j];
+        }
+#pragma unroll
+        for (int v = 0; v < TC; ++v) split8(bf[hf][v], fb[v]);
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+          for (int v = 0; v < TC; ++v) {
+            // smallest terms first, as in the convolution kernel: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[v][2], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][2], fb[v][0], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][1], fb[v][1], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[v][1], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][1], fb[v][0], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[v][0], acc[u][v], 0, 0, 0);
+          }
+      }
+    }
+  } else
   for (long pb = p_begin + (long)wid * (2 * WG_BATCH); pb < p_end; pb += (long)WG_WAVES * 2 * WG_BATCH) {
     float a[WG_BATCH][TN], b[WG_BATCH][TC];
 #pragma unroll
@@ -304,8 +397,13 @@ extern "C" {
 // 32x32 blocks per workgroup tile (wgrad_kernel<TN, TC>): wide where it costs little padding
 static void wgrad_tile(const vam_wgrad& p, int* tn, int* tc) {
   auto pad_ok = [](int n, int t) { return (double)(cdiv(n, 32 * t) * 32 * t) <= 1.15 * n; };
-  int n_ = (p.N % 96 == 0 && p.N % 64 != 0) ? 3 : (pad_ok(p.N, 2) ? 2 : 1);
-  int c_ = (n_ < 3 && pad_ok(p.C, 2)) ? 2 : 1;
+  // bf16-pipe loop: every fragment is split by the wave that loads it, so operand reuse inside the tile pays twice —
+  // 96 x 64 (five fragments for six block pairs) where N is a multiple of 96 (VAMPIC_WGRAD_TILE32=0 keeps 64 x 64 there)
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("VAMPIC_WGRAD_TILE32"); wide = (e && e[0] == '0') ? 0 : 1; }
+  const bool wide_here = wide && p.N % 96 == 0 && pad_ok(p.C, 2);    // (a 16-channel input gains nothing from the taller tile)
+  int n_ = (p.N % 96 == 0 && (wide_here || p.N % 64 != 0)) ? 3 : (pad_ok(p.N, 2) ? 2 : 1);
+  int c_ = ((n_ < 3 || wide_here) && pad_ok(p.C, 2)) ? 2 : 1;
   *tn = n_;
   *tc = c_;
 }
@@ -363,9 +461,17 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   WgradArgs wa;
   for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
   ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
+  static int wg_split = -1;            // VAMPIC_WGRAD=f32: the fp32-pipe loop (A/B measurements)
+  if (wg_split < 0) {
+    const char* e = getenv("VAMPIC_WGRAD");
+    wg_split = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+  }
 #define VAM_WG(TN_, TC_) \
-  if (tn == TN_ && tc == TC_) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);
-  VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1)
+  if (tn == TN_ && tc == TC_) {                                                                                                      \
+    if (wg_split) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 1>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);         \
+    else hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 0>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);                       \
+  }
+  VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1) VAM_WG(3, 2)
 #undef VAM_WG
   if (int rc = check_launch("wgrad_kernel")) return rc;
   if (max_red > 0) {

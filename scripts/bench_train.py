@@ -112,7 +112,7 @@ def main():
         print(json.dumps({"metric": "first_train images/sec (256x256 patches, forward [0,10] + backward of 150 M parameters + Adam)",
                           "value": round(world * a.batch * a.steps / dt, 2), "unit": "images/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 split operands; weight gradients on the fp32 matrix pipe)",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 split operands, forward, data and weight gradients)",
                           "data": "synthetic",
                           "config": {"workload": f"first_train step, quality [0, 10], {a.batch}x3x{a.size}x{a.size} per GPU",
                                      "global_batch": a.batch * world, "trainable_params": n_par, "grad_bytes": 4 * n_par,
