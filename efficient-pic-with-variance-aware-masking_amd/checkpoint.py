@@ -97,8 +97,11 @@ def configure_optimizers(net, args):
     named = dict(net.named_parameters())
     main = sorted(n for n in named if not n.endswith(".quantiles"))
     aux = sorted(n for n in named if n.endswith(".quantiles"))
-    optimizer = torch.optim.Adam((named[n] for n in main), lr=args.learning_rate)
-    aux_optimizer = torch.optim.Adam((named[n] for n in aux), lr=args.aux_learning_rate)
+    # ``args.fused_adam`` (not a reference option; default off): torch's single-kernel Adam — the same update, one launch for
+    # all 1065 tensors instead of a dozen foreach launches per chunk
+    kw = {"fused": True} if getattr(args, "fused_adam", False) else {}
+    optimizer = torch.optim.Adam((named[n] for n in main), lr=args.learning_rate, **kw)
+    aux_optimizer = torch.optim.Adam((named[n] for n in aux), lr=args.aux_learning_rate, **kw)
     return (optimizer, aux_optimizer) if args.training_type == "first_strain" else (optimizer, None)
 
 

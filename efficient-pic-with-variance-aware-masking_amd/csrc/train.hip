@@ -115,6 +115,16 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
     // first_train step: 88.2 vs 82.3 ms of weight gradients — the deep-pixel layers gain 5 %, the pixel-split ones (a few
     // hundred pixels per wave) lose 30 %; choosing per launch landed in between (86.4 ms).  One it is.
     constexpr int NH = SPLIT;
+    // loads without branches: 32-bit byte offsets against wave-uniform descriptors, anything outside the pixel range, the image
+    // or the channel count gets the out-of-range offset and reads 0 (the host sends tensors of 2 GiB or more down the fp32 loop)
+    auto desc = [](const void* q) {
+      const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+      return __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)), 0, 0x7FFFFFFF, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t r_dy = desc(dy), r_x = desc(x);
+    const unsigned OOB = 0x80000000u;
     for (long pb = p_begin + (long)wid * (16 * NH); pb < p_end; pb += (long)WG_WAVES * 16 * NH) {
       float af[NH][TN][8], bf[NH][TC][8];
 #pragma unroll
@@ -127,22 +137,17 @@ __global__ __launch_bounds__(WG_WAVES * 64) void wgrad_kernel(const WgradArgs ar
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const long p = pf + j;
+          const bool pin = p < p_end;
+          const unsigned o_dy = (unsigned)((int)p * ld_dy + n0 + l31) << 2;
 #pragma unroll
-          for (int u = 0; u < TN; ++u) af[hf][u][j] = 0.f;
+          for (int u = 0; u < TN; ++u)
+            af[hf][u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_dy, (int)((pin && n_ok[u]) ? o_dy + 128u * u : OOB), 0, 0));
+          const int iy = oy * stride - pad_y + ty, ix = ox * stride - pad_x + tx;
+          const bool xin = pin && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx;
+          const unsigned o_x = (unsigned)((bi * (int)HWx + iy * Wx + ix) * ld_x + c0 + l31) << 2;
 #pragma unroll
-          for (int v = 0; v < TC; ++v) bf[hf][v][j] = 0.f;
-          if (p < p_end) {
-#pragma unroll
-            for (int u = 0; u < TN; ++u)
-              if (n_ok[u]) af[hf][u][j] = dy[p * ld_dy + n0 + 32 * u + l31];
-            const int iy = oy * stride - pad_y + ty, ix = ox * stride - pad_x + tx;
-            if ((unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx) {
-              const float* xp = x + ((long)bi * HWx + (long)iy * Wx + ix) * ld_x + c0 + l31;
-#pragma unroll
-              for (int v = 0; v < TC; ++v)
-                if (c_ok[v]) bf[hf][v][j] = xp[32 * v];
-            }
-          }
+          for (int v = 0; v < TC; ++v)
+            bf[hf][v][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, (int)((xin && c_ok[v]) ? o_x + 128u * v : OOB), 0, 0));
           ++ox;
           if (ox == W) { ox = 0; ++oy; if (oy == H) { oy = 0; ++bi; } }
         }
@@ -466,9 +471,16 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     const char* e = getenv("VAMPIC_WGRAD");
     wg_split = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
   }
+  bool small = true;                   // the bf16-pipe loop addresses dY and x with 32-bit byte offsets
+  for (int i = 0; i < n_probs; ++i) {
+    const vam_wgrad& p = probs[i];
+    const double px = (double)p.B * (p.stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
+    if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) small = false;
+  }
+  const bool use_split = wg_split && small;
 #define VAM_WG(TN_, TC_) \
   if (tn == TN_ && tc == TC_) {                                                                                                      \
-    if (wg_split) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 1>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);         \
+    if (use_split) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 1>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);         \
     else hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 0>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);                       \
   }
   VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1) VAM_WG(3, 2)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam as the reference constructs it (default here: fused=True)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: start the ranks as children (bench.py)
         from bench import self_launch
@@ -69,6 +70,7 @@ def main():
     net = net.to(dev).train()
     ft.first_train_setup(net)
     net.use_graph = not a.no_graph
+    args.fused_adam = not a.foreach_adam
     opt, _ = configure_optimizers(net, args)
     crit = ft.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device=dev)
     x = vampic.synth.synth_image(a.batch, a.size, a.size, seed=300 + rank).to(dev)
@@ -116,7 +118,7 @@ def main():
                           "data": "synthetic",
                           "config": {"workload": f"first_train step, quality [0, 10], {a.batch}x3x{a.size}x{a.size} per GPU",
                                      "global_batch": a.batch * world, "trainable_params": n_par, "grad_bytes": 4 * n_par,
-                                     "grad_buckets": len(plan.bucket_bounds), "hip_graph": not a.no_graph,
+                                     "grad_buckets": len(plan.bucket_bounds), "hip_graph": not a.no_graph, "adam": "torch fused" if args.fused_adam else "torch foreach",
                                      "loss": round(float(c["loss"].detach()), 5)},
                           "algorithmic_tflops": round(gflop / (dt / a.steps) / 1e3, 2),
                           "phase_ms": {"train_forward": round(t_fwd, 3), "backward_incl_all_reduce": round(t_bwd, 3),
