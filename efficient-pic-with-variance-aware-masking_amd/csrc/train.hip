@@ -435,16 +435,10 @@ int vam_conv_wgrad_plan(const vam_wgrad* p, size_t* workspace_bytes) {
 
 int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   VAM_REQUIRE(probs && n_probs >= 1 && n_probs <= VAM_MAX_WGRAD_GROUP, "vam_conv_wgrad_group: 1..%d problems", VAM_MAX_WGRAD_GROUP);
-  int max_blocks = 0;
   long max_red = 0;
   double flops = 0;
-  int tn = 0, tc = 0;
-  wgrad_tile(probs[0], &tn, &tc);
-  for (int i = 1; i < n_probs; ++i) {               // one tile shape per launch: problems of a group are alike, else 1x1
-    int a_, b_;
-    wgrad_tile(probs[i], &a_, &b_);
-    if (a_ != tn || b_ != tc) { tn = 1; tc = 1; break; }
-  }
+  int tns[VAM_MAX_WGRAD_GROUP], tcs[VAM_MAX_WGRAD_GROUP];
+  bool small = true;                   // the bf16-pipe loop addresses dY and x with 32-bit byte offsets
   for (int i = 0; i < n_probs; ++i) {
     const vam_wgrad& p = probs[i];
     VAM_REQUIRE(p.x && p.dy && p.dw && p.B > 0 && p.H > 0 && p.W > 0 && p.C > 0 && p.N > 0, "vam_conv_wgrad_group: problem %d: bad arguments", i);
@@ -454,38 +448,52 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
     VAM_REQUIRE(p.splits >= 0 && p.splits <= 256 && (p.splits <= 1 || p.workspace), "vam_conv_wgrad_group: problem %d: %d pixel splits need a workspace "
                 "(vam_conv_wgrad_plan)", i, p.splits);
-    const int S = p.splits > 1 ? p.splits : 1;
-    int nb = p.kh * p.kw * cdiv(p.N, 32 * tn) * cdiv(p.C, 32 * tc) * S;
-    max_blocks = nb > max_blocks ? nb : max_blocks;
-    if (S > 1) {
+    wgrad_tile(p, &tns[i], &tcs[i]);
+    if (p.splits > 1) {
       const long tot = (long)p.N * p.C * p.kh * p.kw + p.N;
       max_red = tot > max_red ? tot : max_red;
     }
     flops += 2.0 * p.B * p.H * p.W * (double)p.C * p.N * p.kh * p.kw;
+    const double px = (double)p.B * (p.stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
+    if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) small = false;
   }
-  WgradArgs wa;
-  for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
-  ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
   static int wg_split = -1;            // VAMPIC_WGRAD=f32: the fp32-pipe loop (A/B measurements)
   if (wg_split < 0) {
     const char* e = getenv("VAMPIC_WGRAD");
     wg_split = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
   }
-  bool small = true;                   // the bf16-pipe loop addresses dY and x with 32-bit byte offsets
-  for (int i = 0; i < n_probs; ++i) {
-    const vam_wgrad& p = probs[i];
-    const double px = (double)p.B * (p.stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
-    if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) small = false;
-  }
   const bool use_split = wg_split && small;
+  WgradArgs wa;
+  for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
+  ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);
+  // One launch per tile shape: the problems of a group that share a shape go together.  (A group used to fall back to
+  // 32 x 32 tiles as soon as its problems differed — and the first layer of every slice stack is such a group: its
+  // input segments are the 320-channel hyper-latents and 32 ... 160 channels of y_hat, so the 320-channel problem ran
+  // on the smallest tile too.)
+  bool done[VAM_MAX_WGRAD_GROUP] = {};
+  for (int i0 = 0; i0 < n_probs; ++i0) {
+    if (done[i0]) continue;
+    const int tn = tns[i0], tc = tcs[i0];
+    WgradArgs sub;
+    int n_sub = 0, max_blocks = 0;
+    for (int i = i0; i < n_probs; ++i) {
+      if (done[i] || tns[i] != tn || tcs[i] != tc) continue;
+      done[i] = true;
+      const vam_wgrad& p = probs[i];
+      sub.p[n_sub++] = p;
+      const int S = p.splits > 1 ? p.splits : 1;
+      const int nb = p.kh * p.kw * cdiv(p.N, 32 * tn) * cdiv(p.C, 32 * tc) * S;
+      max_blocks = nb > max_blocks ? nb : max_blocks;
+    }
 #define VAM_WG(TN_, TC_) \
-  if (tn == TN_ && tc == TC_) {                                                                                                      \
-    if (use_split) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 1>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);         \
-    else hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 0>), dim3(max_blocks, n_probs), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, wa);                       \
-  }
-  VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1) VAM_WG(3, 2)
+    if (tn == TN_ && tc == TC_) {                                                                                                      \
+      if (use_split) hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 1>), dim3(max_blocks, n_sub), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, sub); \
+      else hipLaunchKernelGGL((wgrad_kernel<TN_, TC_, 0>), dim3(max_blocks, n_sub), dim3(WG_WAVES * 64), 0, (hipStream_t)stream, sub);           \
+    }
+    VAM_WG(1, 1) VAM_WG(2, 1) VAM_WG(1, 2) VAM_WG(2, 2) VAM_WG(3, 1) VAM_WG(3, 2)
 #undef VAM_WG
-  if (int rc = check_launch("wgrad_kernel")) return rc;
+    if (int rc = check_launch("wgrad_kernel")) return rc;
+  }
   if (max_red > 0) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(max_red, 256) > 1024 ? 1024 : cdiv(max_red, 256), n_probs), dim3(256), 0,
                        (hipStream_t)stream, wa);
