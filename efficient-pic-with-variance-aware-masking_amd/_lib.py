@@ -79,6 +79,11 @@ class VamConv(C.Structure):
     ]
 
 
+class VamPackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bias", C.c_int32), ("mode", C.c_int32), ("phase", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32), ("n", C.c_int32), ("pad_", C.c_int32)]
+
+
 class VamResunit(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_int32), ("ldo", C.c_int32),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
@@ -126,6 +131,7 @@ _SIGNATURES = {
     "vam_dequantize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vam_pack_group": (C.c_int, [C.POINTER(VamPackJob), C.c_int, C.c_void_p]),
     "vam_absmax": (C.c_int, [C.POINTER(VamSeg), C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_sqdiff_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "vam_eb_forward_noise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]),

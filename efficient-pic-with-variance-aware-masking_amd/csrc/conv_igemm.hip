@@ -1267,10 +1267,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
 
 // bf16x3 layout: [tap][32-channel chunk][Npad][12 chunks][8 bf16]; chunk (p*4 + g) holds plane p (hi/mid/lo) of
 // channels 8g..8g+7 of the 32-channel chunk.  The three planes sum to the fp32 weight exactly.
-__global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
-                                        int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total, int dual) {
-  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= total) return;
+__device__ __forceinline__ void pack_bf3_element(long d, const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
+                                                 int phase, int kh, int kw, int cin, int n, int npad, int kc32, int dual) {
   int kk = (int)(d % 32);
   long r = d / 32;
   int nn = (int)(r % npad);
@@ -1294,6 +1292,13 @@ __global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned 
   dst[row + (0 * 4 + g) * 8 + e] = (unsigned short)(hb >> 16);
   dst[row + (1 * 4 + g) * 8 + e] = (unsigned short)(mb >> 16);
   dst[row + (2 * 4 + g) * 8 + e] = (unsigned short)(lb >> 16);
+}
+
+__global__ void pack_weights_bf3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int mode,
+                                        int phase, int kh, int kw, int cin, int n, int npad, int kc32, long total, int dual) {
+  long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  pack_bf3_element(d, src, dst, mode, phase, kh, kw, cin, n, npad, kc32, dual);
 }
 
 // fp16x2 (MODE 3): per output channel n the power of two 2^s_n that maps max |w[n, :]| into [2^14, 2^15); out[n] = 2^-s_n
@@ -1388,9 +1393,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ src, unsigned
   dst[d] = __builtin_bit_cast(unsigned short, h);
 }
 
-__global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void pack_bias_element(int i, const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
   float v;
   if (mode == VAM_PACK_PS2) {
     int cq = n / 4;
@@ -1409,6 +1412,31 @@ __global__ void pack_bias_kernel(const float* __restrict__ src, float* __restric
     v = src[i];
   }
   dst[i] = v;
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pack_bias_element(i, src, dst, mode, n);
+}
+
+// Many small repacks as one launch (training: every trained layer is repacked after every optimiser step — 1,250 launches
+// of ~4.5 us per first_train step when issued one by one).  blockIdx.y = job; a job's blocks stride over its elements.
+struct PackJobD {
+  const float* src;
+  void* dst;
+  long total;
+  int kind, mode, phase, kh, kw, cin, n, npad, kc32, dual;
+};
+struct PackGroupArgs {
+  PackJobD j[VAM_MAX_PACK_GROUP];
+};
+__global__ __launch_bounds__(256) void pack_group_kernel(const PackGroupArgs a) {
+  const PackJobD& j = a.j[blockIdx.y];
+  for (long d = (long)blockIdx.x * 256 + threadIdx.x; d < j.total; d += (long)gridDim.x * 256) {
+    if (j.kind == 0) pack_bf3_element(d, j.src, reinterpret_cast<unsigned short*>(j.dst), j.mode, j.phase, j.kh, j.kw, j.cin, j.n, j.npad, j.kc32, j.dual);
+    else pack_bias_element((int)d, j.src, reinterpret_cast<float*>(j.dst), j.mode, j.n);
+  }
 }
 
 static int g_force[3] = {0, 0, 0};   // tuning hook: forced BM / BN / BK (0 = automatic)
@@ -1839,6 +1867,52 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
 #undef VAM_CFG
   set_error("vam_conv_group: no kernel configuration for BM=%d BN=%d", bm, best_bn);
   return VAM_EINVAL;
+}
+
+int vam_pack_group(const vam_pack_job* jobs, int n_jobs, void* stream) {
+  VAM_REQUIRE(jobs && n_jobs >= 1, "vam_pack_group: no jobs");
+  if (conv_mode() != 1) {                      // other arithmetic modes: one by one through the ordinary entry points
+    for (int i = 0; i < n_jobs; ++i) {
+      const vam_pack_job& q = jobs[i];
+      int rc = q.bias ? vam_pack_bias(q.src, (float*)q.dst, q.mode, q.n, stream)
+                      : vam_pack_conv_weights(q.src, (float*)q.dst, q.mode, q.phase, q.kh, q.kw, q.cin, q.n, stream);
+      if (rc != VAM_OK) return rc;
+    }
+    return VAM_OK;
+  }
+  for (int i0 = 0; i0 < n_jobs; i0 += VAM_MAX_PACK_GROUP) {
+    const int cnt = n_jobs - i0 < VAM_MAX_PACK_GROUP ? n_jobs - i0 : VAM_MAX_PACK_GROUP;
+    PackGroupArgs a;
+    long max_total = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const vam_pack_job& q = jobs[i0 + i];
+      PackJobD& j = a.j[i];
+      VAM_REQUIRE(q.src && q.dst && q.n > 0, "vam_pack_group: job %d: bad arguments", i0 + i);
+      j.src = q.src; j.dst = q.dst; j.mode = q.mode; j.phase = q.phase; j.kh = q.kh; j.kw = q.kw; j.cin = q.cin; j.n = q.n;
+      if (q.bias) {
+        j.kind = 1; j.total = q.n; j.npad = j.kc32 = j.dual = 0;
+      } else {
+        VAM_REQUIRE(q.kh > 0 && q.kw > 0 && q.cin > 0 && q.mode >= VAM_PACK_CONV && q.mode <= VAM_PACK_GDN_T, "vam_pack_group: job %d: bad geometry / mode", i0 + i);
+        if (q.mode == VAM_PACK_PS2) VAM_REQUIRE(q.n % 4 == 0, "PS2 pack needs N %% 4 == 0");
+        if (q.mode == VAM_PACK_DECONV5S2 && q.phase < 0) VAM_REQUIRE(q.n % 4 == 0 && q.kh == 3 && q.kw == 3, "merged deconv pack needs 3x3, N=4*Cout");
+        if (q.mode == VAM_PACK_DECONV5S2 && q.phase >= 0)
+          VAM_REQUIRE(q.phase < 4 && q.kh == ((q.phase >> 1) ? 2 : 3) && q.kw == ((q.phase & 1) ? 2 : 3), "deconv phase %d needs kh/kw = 3|2", q.phase);
+        if (q.mode == VAM_PACK_GDN || q.mode == VAM_PACK_GDN_T) VAM_REQUIRE(q.kh == 1 && q.kw == 1 && q.cin == q.n, "GDN pack is 1x1 and square");
+        j.kind = 0;
+        j.npad = (q.n + 31) / 32 * 32;
+        j.kc32 = (q.cin + 31) / 32;
+        j.dual = dual_tap(q.cin, q.kh * q.kw) ? 1 : 0;
+        j.total = j.dual ? (long)((q.kh * q.kw + 1) / 2) * j.npad * 32 : (long)q.kh * q.kw * j.kc32 * j.npad * 32;
+      }
+      if (j.total > max_total) max_total = j.total;
+    }
+    long bx = cdiv(max_total, 256 * 4);          // ~4 elements per thread of the largest job
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(pack_group_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a);
+    if (int rc = check_launch("pack_group_kernel")) return rc;
+  }
+  return VAM_OK;
 }
 
 int vam_absmax(const vam_seg* segs, int n_seg, long n_pix, int32_t* cell, void* stream) {

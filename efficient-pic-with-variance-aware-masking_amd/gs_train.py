@@ -187,7 +187,11 @@ class TransformPacks:
 
     def record_refresh(self, plan: E.Plan):
         fns = list(self._refresh)
-        plan.call(lambda: [fn() for fn in fns], f"repack {len(fns)} trained layers")
+        def run():
+            with ops.pack_batch():               # one grouped launch per 32 repacks instead of one launch each
+                for fn in fns:
+                    fn()
+        plan.call(run, f"repack {len(fns)} trained layers")
 
 
 # ============================================================================= forward (taped)

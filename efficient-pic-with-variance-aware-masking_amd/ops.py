@@ -218,16 +218,49 @@ def pack_weights(src: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin
     return dst
 
 
+_PACK_JOBS: Optional[list] = None      # inside ``pack_batch()``: deferred (job, keep-alive) pairs
+
+
+class pack_batch:
+    """``with ops.pack_batch(): ...`` — the repack calls inside are collected and issued as grouped launches
+    (``vam_pack_group``) when the block ends, on the stream that is current then.  Nothing may read the packed buffers
+    inside the block."""
+
+    def __enter__(self):
+        global _PACK_JOBS
+        self.prev, _PACK_JOBS = _PACK_JOBS, []
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_JOBS
+        jobs, _PACK_JOBS = _PACK_JOBS, self.prev
+        if exc[0] is None and jobs:
+            arr = (L.VamPackJob * len(jobs))(*[j for j, _ in jobs])
+            L.check(L.load().vam_pack_group(arr, len(jobs), stream_ptr()), "vam_pack_group")
+        return False
+
+
+def _pack_job(src: torch.Tensor, dst: torch.Tensor, bias: bool, mode: int, phase: int, kh: int, kw: int, cin: int, n: int) -> bool:
+    if _PACK_JOBS is None:
+        return False
+    j = L.VamPackJob()
+    j.src, j.dst, j.bias, j.mode, j.phase, j.kh, j.kw, j.cin, j.n = src.data_ptr(), dst.data_ptr(), int(bias), mode, phase, kh, kw, cin, n
+    _PACK_JOBS.append((j, (src, dst)))
+    return True
+
+
 def repack_conv(conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], pk: "Packed", dgrad: bool = False):
     """Refresh ``pk`` IN PLACE from the (trained) parameters: plans keep pointing at the same packed buffers
     while the optimiser updates the weights between steps."""
     lib = L.load()
     assert conv_weight.is_cuda and conv_weight.is_contiguous() and conv_weight.dtype == torch.float32
     mode = L.PACK_CONV_DGRAD if dgrad else L.PACK_CONV
-    L.check(lib.vam_pack_conv_weights(conv_weight.data_ptr(), pk.w.data_ptr(), mode, 0, pk.kh, pk.kw, pk.cin, pk.n,
-                                      stream_ptr()), "vam_pack_conv_weights")
+    if not _pack_job(conv_weight, pk.w, False, mode, 0, pk.kh, pk.kw, pk.cin, pk.n):
+        L.check(lib.vam_pack_conv_weights(conv_weight.data_ptr(), pk.w.data_ptr(), mode, 0, pk.kh, pk.kw, pk.cin, pk.n,
+                                          stream_ptr()), "vam_pack_conv_weights")
     if not dgrad and conv_bias is not None:
-        L.check(lib.vam_pack_bias(conv_bias.data_ptr(), pk.b.data_ptr(), L.PACK_CONV, pk.n, stream_ptr()), "vam_pack_bias")
+        if not _pack_job(conv_bias, pk.b, True, L.PACK_CONV, 0, 0, 0, 0, pk.n):
+            L.check(lib.vam_pack_bias(conv_bias.data_ptr(), pk.b.data_ptr(), L.PACK_CONV, pk.n, stream_ptr()), "vam_pack_bias")
 
 
 def pack_bias(src: torch.Tensor, mode: int, n: int) -> torch.Tensor:
@@ -638,11 +671,15 @@ def colsum(dy: View, out: torch.Tensor, workspace: Optional[torch.Tensor] = None
 def repack_weights(src: torch.Tensor, dst: torch.Tensor, mode: int, phase: int, kh: int, kw: int, cin: int, n: int):
     """vam_pack_conv_weights into an EXISTING packed buffer (training: the optimiser changed ``src`` in place)."""
     assert src.is_cuda and src.is_contiguous() and src.dtype == torch.float32
+    if _pack_job(src, dst, False, mode, phase, kh, kw, cin, n):
+        return
     L.check(L.load().vam_pack_conv_weights(src.data_ptr(), dst.data_ptr(), mode, phase, kh, kw, cin, n, stream_ptr()),
             "vam_pack_conv_weights")
 
 
 def repack_bias(src: torch.Tensor, dst: torch.Tensor, mode: int, n: int):
+    if _pack_job(src, dst, True, mode, 0, 0, 0, 0, n):
+        return
     L.check(L.load().vam_pack_bias(src.data_ptr(), dst.data_ptr(), mode, n, stream_ptr()), "vam_pack_bias")
 
 

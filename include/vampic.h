@@ -145,6 +145,17 @@ int vam_pack_conv_weights(const float* src, float* dst, int mode, int phase,
 size_t vam_conv_wpack_bf16_bytes(int kh, int kw, int cin, int n);
 int vam_pack_conv_weights_bf16(const float* src, void* dst, int mode, int phase, int kh, int kw, int cin, int n,
                                void* stream);
+/* Many repacks as ONE launch (training refreshes every trained layer's packed weights after every optimiser step).
+ * bias != 0: a vam_pack_bias job (kh, kw, cin, phase ignored); else a vam_pack_conv_weights job. */
+#define VAM_MAX_PACK_GROUP 32
+typedef struct vam_pack_job {
+  const float* src;
+  void* dst;
+  int32_t bias;
+  int32_t mode, phase, kh, kw, cin, n;
+  int32_t pad_;
+} vam_pack_job;
+int vam_pack_group(const vam_pack_job* jobs, int n_jobs, void* stream);
 /* bias helpers: PS2 permutation / GDN beta reparam (max(b, sqrt(1e-6+2^-36))^2 - 2^-36) /
  * merged-deconv replication (4x). mode as above. */
 int vam_pack_bias(const float* src, float* dst, int mode, int n, void* stream);
