@@ -205,3 +205,31 @@ def test_memset_zero_is_a_kernel_with_word_granularity():
     assert lib.vam_memset_zero(C.c_void_p(0x1002), 8, None) == -1
     assert lib.vam_memset_zero(C.c_void_p(0x1000), 6, None) == -1
     assert b"multiples of 4" in lib.vam_last_error()
+
+
+def test_weight_gradient_planning_is_host_arithmetic():
+    """``vam_conv_wgrad_plan`` (pixel splits + workspace of a weight-gradient problem) is pure host arithmetic on the
+    problem's extents: callable without a GPU, deterministic, and consistent with what the launch will need —
+    workspace = splits x (N C taps + N) floats, no split for problems that already fill the chip, never more splits
+    than 2048-pixel ranges.  (The tile the kernel picks — 96x64 where N is a multiple of 96 and C >= 64 — enters through
+    the number of weight tiles.)"""
+    import ctypes
+    lib = L.load()
+
+    def plan(B, H, W, C_, N, k):
+        p = L.VamWgrad()
+        p.B, p.H, p.W, p.C, p.N, p.kh, p.kw = B, H, W, C_, N, k, k
+        nbytes = ctypes.c_size_t(0)
+        s = lib.vam_conv_wgrad_plan(ctypes.byref(p), ctypes.byref(nbytes))
+        return s, nbytes.value
+
+    for shape in [(32, 64, 64, 192, 192, 5), (32, 64, 64, 96, 96, 3), (32, 16, 16, 320, 224, 3), (32, 128, 128, 192, 192, 1),
+                  (32, 16, 16, 64, 32, 3), (1, 16, 16, 64, 32, 3)]:
+        B, H, W, C_, N, k = shape
+        s, nb = plan(*shape)
+        assert (s, nb) == plan(*shape)
+        assert 1 <= s <= 256 and s <= max(1, B * H * W // 2048), shape
+        assert nb == (0 if s == 1 else s * (N * C_ * k * k + N) * 4), shape
+    assert plan(1, 16, 16, 64, 32, 3)[0] == 1                      # 256 pixels: nothing to split
+    assert plan(32, 128, 128, 192, 192, 1)[0] > 8                  # a 1x1 layer on 524288 pixels has 2 x 3 weight tiles
+    assert ctypes.sizeof(L.VamPackJob) == 48                       # include/vampic.h: two pointers + eight int32
