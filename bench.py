@@ -136,6 +136,40 @@ def self_launch(argv, n: int, script: str = None) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def train_legs(dev, dist, forced):
+    """BASELINE configs[3] / [4] on one GPU's share: a first_train step (forward [0, 10] of 32x3x256x256 + backward of all
+    150 M parameters + clip + Adam; scripts/bench_train.py) and a REM fine-tune step (16x3x256x256, q = 2.5, check level
+    0.75; scripts/bench_finetune.py), timed by those scripts' own ``measure`` (hipGraph replay, 2 warm-up + 5 timed
+    steps).  Returns {"first_train": {...}, "rem_finetune": {...}} for the line's ``train`` object."""
+    import gc
+    import importlib.util
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    out = {}
+    for key, mod, kw in (("first_train", "bench_train", dict(batch=32, size=256, steps=5, warmup=2)),
+                         ("rem_finetune", "bench_finetune", dict(batch=16, size=256, steps=5, warmup=2))):
+        t0 = time.perf_counter()
+        print(f"[bench] train leg {key} ...", file=sys.stderr, flush=True)
+        r = load(mod).measure(dev, 0, 1, dist, forced=forced, **kw)
+        rec = {"workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"],
+               "ms_per_step_gc_unfrozen": r["ms_per_step_gc_unfrozen"], "images_per_s": r["value"], "steps": r["steps"],
+               "warmup": r["warmup"], "phase_ms": r["phase_ms"], "dtype": r["dtype"], "collectives": r["collectives"],
+               "loss": r["config"]["loss"], "trainable_params": r["config"]["trainable_params"]}
+        if "algorithmic_tflops" in r:
+            rec["tflops"] = r["algorithmic_tflops"]
+            rec["frac_of_split_ceiling"] = round(r["algorithmic_tflops"] / (BF16_MFMA_PEAK_TFLOPS / BF16X3_PRODUCTS), 4)
+        out[key] = rec
+        gc.collect()
+        print(f"[bench] train leg {key}: {rec['ms_per_step']} ms/step ({time.perf_counter() - t0:.0f} s incl. plan build)",
+              file=sys.stderr, flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +186,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-storage measurement of the default run")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the secondary training measurements of the default run (BASELINE configs[3] / [4]: first_train and "
+                         "REM fine-tune steps on this GPU's share of the batch)")
     ap.add_argument("--dry", action="store_true",
                     help="rehearse rank setup / sharding / aggregation without touching a GPU (CPU test of the N>1 entry)")
     a = ap.parse_args()
@@ -182,6 +219,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
+    from vampic import sharding
+    forced = dist is None and sharding.init_single_rank_group(dev)     # VAMPIC_FORCE_COLLECTIVES=1: a 1-rank RCCL group
+    if forced:
+        import torch.distributed as dist
     red_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
     import vampic
@@ -212,7 +253,6 @@ def main():
             out = net.forward_single_quality(x, q, clone=False)
         sync_all()
         dt = time.perf_counter() - t0
-    from vampic import sharding
     dt = sharding.max_over_ranks(dt, red_dev)                 # slowest rank (RCCL all-reduce MAX)
     ms_step = dt / a.steps * 1e3
     mp_s = sharding.whole_job_megapixels_per_s(B, H, W, a.steps, world, dt)
@@ -329,6 +369,11 @@ def main():
                     "mask_xor": int((o16["mask"] != o32["mask"]).sum()), "mask_elements": o32["mask"].numel(),
                     "d_psnr_db": round(ps(o16) - ps(o32), 5), "d_bpp": round(bp(o16) - bp(o32), 6)}
         del net16
+    # ---- secondary: the training configurations (BASELINE configs[3] first_train, configs[4] REM fine-tune) on this GPU's share
+    # of their batches, 5 timed steps each, so that the driver's one line carries them too.  The headline is unchanged.
+    train_rec = None
+    if rank == 0 and world == 1 and a.dtype == "f32" and not a.no_train and (B, H, W) == (32, 256, 256):
+        train_rec = train_legs(dev, dist, forced)
     if rank == 0:
         bpp = -out["log2_likelihood_sum"].sum().item() / (B * H * W)
         line = {"metric": "megapixels/sec encode+decode (g_a->mask->g_s) at 256x256 bs32",
@@ -350,6 +395,10 @@ def main():
             line["vs_fp32"] = vs_fp32
         if bf16_rec is not None:
             line["bf16"] = bf16_rec
+        if train_rec is not None:
+            line["train"] = train_rec
+        if forced:
+            line["collectives"] = "forced (1-rank nccl group: barrier + max-over-ranks all-reduce issued on RCCL)"
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, H, W, q)
         print(json.dumps(line), flush=True)

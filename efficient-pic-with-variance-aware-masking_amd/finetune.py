@@ -241,6 +241,30 @@ class ScalableRateDistortionLoss(nn.Module):
         return out
 
 
+def clip_grad_norm_(model, max_norm: float):
+    """``torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`` (training/step.py:98) — as ONE reduction when the
+    gradients of all parameters are views of the first-stage plan's flat buffer (models._FullTrainFn.backward hands them
+    out that way; padding between tensors is zero), instead of a walk over 1065 tensors.  Anything else (a frozen
+    subset, gradients from another source such as the aux loss, accumulated gradients) takes torch's own routine."""
+    plans = [p for k, p in getattr(model, "_plans", {}).items() if k[0] == "full_train" and getattr(p, "handout", None) is not None]
+    if len(plans) == 1 and plans[0].handout[2]:
+        flat, n_out, _ = plans[0].handout
+        base, ok, n = flat.untyped_storage().data_ptr(), True, 0
+        for p in model.parameters():
+            g = p.grad
+            if g is None:
+                continue
+            n += 1
+            if g.untyped_storage().data_ptr() != base:
+                ok = False
+                break
+        if ok and n == n_out:
+            total = torch.linalg.vector_norm(flat)
+            flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+            return total
+    return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+
+
 def first_train_setup(model):
     """train.py:146-149 / :214-226: the first stage freezes nothing."""
     for p in model.parameters():
@@ -260,7 +284,7 @@ def first_train_step(model, criterion, batch: torch.Tensor, optimizer, list_qual
     optimizer.zero_grad()
     if aux_optimizer is not None:
         aux_optimizer.zero_grad()
-    if S.world_size() > 1 and getattr(model, "grad_reducer", None) is None:
+    if S.collectives_active() and getattr(model, "grad_reducer", None) is None:
         model.grad_reducer = S.BucketReducer()
     out = model(batch, quality=list(list_quality), training=True, noise=noise)
     crit = criterion(out, batch)
@@ -270,7 +294,7 @@ def first_train_step(model, criterion, batch: torch.Tensor, optimizer, list_qual
         aux.backward()
         aux_optimizer.step()
     if clip_max_norm > 0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
+        clip_grad_norm_(model, clip_max_norm)
     optimizer.step()
     return crit
 
@@ -334,7 +358,7 @@ def refine_gs_ga_step(model, criterion, batch: torch.Tensor, optimizer, quality:
     on the first batch.  This mirrors what that line evidently means to do (keep the result)."""
     from . import sharding as S
     optimizer.zero_grad()
-    if S.world_size() > 1 and getattr(model, "grad_reducer", None) is None:
+    if S.collectives_active() and getattr(model, "grad_reducer", None) is None:
         model.grad_reducer = S.BucketReducer()
     out = model.forward_single_quality(batch, quality=quality, training=True, noise=noise)
     crit = criterion(out, batch, lmbda=lmbda)

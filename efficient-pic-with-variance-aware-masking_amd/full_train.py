@@ -168,10 +168,14 @@ def _conv5_bwd(bw, pk, r: dict, dy: View, grads, keep: list) -> Optional[View]:
         # w[n,c,2ty+py,2tx+px] (ops.pack_conv5s2_rgb); the image has no gradient
         n = m.out_channels
         t16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=gw.device)
-        keep.append(t16)
+        g6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=gw.device)
+        keep += [t16, g6]
         bw.wgrad(ops.wgrad_problems([x], dy, t16, gb))
-        bw.call(lambda: gw.copy_(t16[:, :12].reshape(n, 2, 2, 3, 3, 3).permute(0, 3, 4, 1, 5, 2).reshape(n, 3, 6, 6)[:, :, :5, :5]),
-                "first-layer weight gradient: s2d -> 5x5")
+
+        def scatter():          # captured step: strided copies between pre-allocated buffers, no temporaries
+            g6.view(n, 3, 3, 2, 3, 2).copy_(t16[:, :12].view(n, 2, 2, 3, 3, 3).permute(0, 3, 4, 1, 5, 2))
+            gw.copy_(g6[:, :, :5, :5])
+        bw.call(scatter, "first-layer weight gradient: s2d -> 5x5")
         return None
     bw.wgrad(ops.wgrad_problems([x], dy, gw, gb, stride=2))
     dx = bw.buf(x.B, x.H, x.W, x.C)

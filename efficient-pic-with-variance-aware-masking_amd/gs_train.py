@@ -96,9 +96,9 @@ class TransformPacks:
         w6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=c.weight.device)
         self.keep += [w16, w6]
 
-        def gather():
+        def gather():           # runs inside the captured refresh step: strided copies between views, no temporaries
             w6[:, :, :5, :5].copy_(c.weight.detach())
-            w16[:, :12].copy_(w6.reshape(n, 3, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(n, 12, 3, 3))
+            w16[:, :12].view(n, 2, 2, 3, 3, 3).copy_(w6.view(n, 3, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4))
         gather()
         f = ops.Packed(ops.pack_weights(w16, L.PACK_CONV, 0, 3, 3, 16, n), ops.pack_bias(c.bias, L.PACK_CONV, n), 3, 3, 16, n, 1, 1, 1)
         self.f[id(c)] = f

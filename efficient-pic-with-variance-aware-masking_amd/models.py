@@ -813,9 +813,15 @@ class _FullTrainFn(torch.autograd.Function):
         if ctx.plan.generation != ctx.generation:
             raise RuntimeError("the training plan for this shape ran again before this backward(): its tape now belongs to "
                                "the later forward — call loss.backward() before the next training forward of this shape")
-        views = ctx.plan.backward(g_xhat, g_lik, g_z, ctx.use_graph, ctx.reducer)
+        plan = ctx.plan
+        plan.backward(g_xhat, g_lik, g_z, ctx.use_graph, ctx.reducer)
         need = ctx.needs_input_grad[6:]
-        return (None,) * 6 + tuple(v.clone() if n else None for v, n in zip(views, need))
+        # ONE copy of the flat gradient buffer (the plan overwrites its own at the next backward); every parameter's
+        # gradient is a view of the copy, so the clip can run as one reduction over it (finetune.clip_grad_norm_)
+        flat = plan.flat.clone()
+        plan.handout = (flat, sum(1 for n in need if n), all(need))
+        return (None,) * 6 + tuple(flat[o:o + p.numel()].view(p.shape) if n else None
+                                   for o, p, n in zip(plan.offsets, plan.params, need))
 
 
 class _FsqPlan:

@@ -140,6 +140,7 @@ def amax_prepare(chunk: Sequence["L.VamConv"]):
     base = cells.data_ptr()
     todo = []
     for i, c in enumerate(chunk):
+        c._amax_cells = cells            # the structs point into ``cells``: it lives as long as they do
         if c.flags & (L.CONV_W_BF16 | L.CONV_IN_BF3):
             continue
         for k in range(c.n_seg):
@@ -745,6 +746,8 @@ class Graph:
         drain_graveyard()
         lib = L.load()
         s = stream_ptr()
+        dev = torch.cuda.current_device()
+        n_alloc = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
         L.check(lib.vam_graph_begin(s), "vam_graph_begin")
         _CAPTURING += 1
         try:
@@ -753,6 +756,14 @@ class Graph:
             _CAPTURING -= 1
             rc = lib.vam_graph_end(s, C.byref(self.exec))
         L.check(rc, "vam_graph_end")
+        # The capture is a raw hipStreamBeginCapture torch's caching allocator knows nothing about: a tensor allocated by a
+        # captured step would be returned to the pool while the graph keeps its address.  Plans allocate while they are
+        # BUILT, never while they run — enforce it.
+        n_new = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0) - n_alloc
+        if n_new:
+            self.close()
+            raise RuntimeError(f"{n_new} device allocation(s) inside a hipGraph capture: a captured step created a torch temporary "
+                               "(pre-allocate it when the plan is built and write through views)")
 
     def launch(self):
         self.last_stream = torch.cuda.current_stream()

@@ -4,9 +4,41 @@ shards across ranks with NO data-path collective.  The only communication is the
 scalar aggregation below (RCCL when the backend is "nccl", gloo in the CPU tests)."""
 from __future__ import annotations
 
+import os
 from typing import List, Tuple
 
 import torch
+
+
+def collectives_active() -> bool:
+    """True when the exchange steps must issue their collectives: a process group exists and either the job has more
+    than one rank or ``VAMPIC_FORCE_COLLECTIVES=1`` asks for them at world size 1 (a 1-rank ``nccl`` group on a single
+    GPU runs communicator init, the comm-stream / event ordering against the backward's graph segments, ``work.wait()``
+    and the division exactly as an N-rank job does; sums over one rank are the identity, so results do not change)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("VAMPIC_FORCE_COLLECTIVES", "0") == "1"
+
+
+def init_single_rank_group(device=None, backend: str = "nccl") -> bool:
+    """``VAMPIC_FORCE_COLLECTIVES=1`` without a launcher: make this process a 1-rank process group (RCCL on ``device``)
+    so that the exchange steps run their collectives.  Returns True when a group was created."""
+    import torch.distributed as dist
+    if os.environ.get("VAMPIC_FORCE_COLLECTIVES", "0") != "1" or not dist.is_available() or dist.is_initialized():
+        return False
+    import socket
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = torch.device(device)
+    dist.init_process_group(backend, rank=0, world_size=1, **kw)
+    return True
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -20,7 +52,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def max_over_ranks(value: float, device="cpu") -> float:
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -29,7 +61,7 @@ def max_over_ranks(value: float, device="cpu") -> float:
 
 def sum_over_ranks(values: List[float], device="cpu") -> List[float]:
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return [float(v) for v in values]
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -54,7 +86,7 @@ def all_reduce_gradients(params) -> int:
     A parameter that received a gradient on no rank keeps ``grad = None`` (the optimiser then skips it, as in a
     single-process run).  Returns the number of bytes reduced (0 when not distributed)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return 0
     params = list(params)
     if not params:
@@ -89,7 +121,7 @@ def broadcast_choice(n_choices: int, rng, device="cpu") -> int:
     across ranks, or the gradient bucket would mix different modules' gradients."""
     import torch.distributed as dist
     idx = rng.randint(0, n_choices - 1)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return idx
     t = torch.tensor([idx], dtype=torch.int64, device=device)
     dist.broadcast(t, src=0)
@@ -145,7 +177,7 @@ class BucketReducer:
     def __call__(self, idx: int, flat_slice: torch.Tensor, stream=None):
         import torch.distributed as dist
         self.log.append((idx, flat_slice.numel()))
-        if world_size() == 1:
+        if not collectives_active():
             return
         if flat_slice.is_cuda:
             if self.comm is None:

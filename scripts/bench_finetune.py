@@ -24,6 +24,87 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def measure(dev, rank=0, world=1, dist=None, batch=16, size=256, steps=10, warmup=3, quality=2.5, no_graph=False, two_pass=False,
+            forced=False, freeze_gc=True):
+    """Time ``steps`` REM fine-tune steps on this rank's synthetic shard; returns the record rank 0 prints (bench.py embeds
+    it in its own line as ``train.rem_finetune``)."""
+    import vampic
+    from vampic import finetune as ft, sharding
+    args = argparse.Namespace(model="rem", check_levels=[0.75], mu_std=True, dimension="middle", N=192, M=640,
+                              multiple_decoder=True, multiple_encoder=True, multiple_hyperprior=True, dim_chunk=32,
+                              division_dimension=[320, 640], mask_policy="point-based-std", support_progressive_slices=5,
+                              delta_encode=True, total_mu_rep=True, all_scalable=True)
+    net = vampic.get_model(args, "cpu")
+    torch.nn.Module.load_state_dict(net, vampic.synth.synth_state_dict(net.state_dict(), seed=0))
+    net = net.to(dev).train()
+    net.freeze_all()
+    net.unfreeze_rems()
+    net.use_graph = not no_graph
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    crit = ft.RateLoss()
+    x = vampic.synth.synth_image(batch, size, size, seed=200 + rank).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(warmup, 1)):
+        c = ft.finetune_step(net, crit, x, opt, quality, [0.75], fused=not two_pass)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = ft.finetune_step(net, crit, x, opt, quality, [0.75], fused=not two_pass)
+    sync()
+    dt_unfrozen = time.perf_counter() - t0
+    # see scripts/bench_train.py: the headline is measured after gc.freeze(); the un-frozen time of the same steps
+    # was taken just above and is reported beside it
+    import gc
+    if freeze_gc:
+        gc.collect()
+        gc.freeze()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = ft.finetune_step(net, crit, x, opt, quality, [0.75], fused=not two_pass)
+    sync()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
+
+    # phase split on rank 0 (events on the current stream; the plans join it on entry and exit)
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(dev)
+        return r, (time.perf_counter() - t) * 1e3
+    with torch.no_grad():
+        ck, t_ck = timed(lambda: net.ExtractChekpointRepr(x, quality=0.75, rc=False))
+    opt.zero_grad()
+    if two_pass:
+        out, t_fwd = timed(lambda: net.forward_single_quality(x, quality=quality, training=True, checkpoint_ref=ck))
+    else:
+        t_ck = 0.0
+        out, t_fwd = timed(lambda: net.forward_finetune(x, quality))
+    loss = crit(out, x)["loss"]
+    _, t_bwd = timed(loss.backward)
+    _, t_ar = timed(lambda: sharding.all_reduce_gradients(p for p in net.parameters() if p.requires_grad))
+    _, t_opt = timed(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0), opt.step()))
+    n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    gc.unfreeze()
+    return ({"metric": "REM fine-tune images/sec (256x256 patches, rate loss, Adam)",
+                          "value": round(world * batch * steps / dt, 2), "unit": "images/s", "n_gpus": world,
+                          "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_gc_unfrozen": round(dt_unfrozen / steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "collectives": ("forced (1-rank nccl group)" if forced else ("nccl" if world > 1 else "none")),
+                          "config": {"workload": f"REM fine-tune step q={quality}, check level 0.75, {batch}x3x{size}x{size} per GPU",
+                                     "global_batch": batch * world, "trainable_params": n_par,
+                                     "grad_bucket_bytes": 4 * n_par, "hip_graph": not no_graph, "fused_checkpoint": not two_pass,
+                                     "loss": round(float(c["loss"].detach()), 5)},
+                          "phase_ms": {"checkpoint_forward": round(t_ck, 3), "train_forward": round(t_fwd, 3),
+                                       "backward": round(t_bwd, 3), "grad_all_reduce": round(t_ar, 3),
+                                       "clip_adam": round(t_opt, 3)}})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,76 +135,13 @@ def main():
     assert world == a.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    import vampic
-    from vampic import finetune as ft, sharding
-    args = argparse.Namespace(model="rem", check_levels=[0.75], mu_std=True, dimension="middle", N=192, M=640,
-                              multiple_decoder=True, multiple_encoder=True, multiple_hyperprior=True, dim_chunk=32,
-                              division_dimension=[320, 640], mask_policy="point-based-std", support_progressive_slices=5,
-                              delta_encode=True, total_mu_rep=True, all_scalable=True)
-    net = vampic.get_model(args, "cpu")
-    torch.nn.Module.load_state_dict(net, vampic.synth.synth_state_dict(net.state_dict(), seed=0))
-    net = net.to(dev).train()
-    net.freeze_all()
-    net.unfreeze_rems()
-    net.use_graph = not a.no_graph
-    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
-    crit = ft.RateLoss()
-    x = vampic.synth.synth_image(a.batch, a.size, a.size, seed=200 + rank).to(dev)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(max(a.warmup, 1)):
-        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
-    sync()
-    # The plans hold ~1e6 long-lived Python objects (problem structs, views): a full (generation-2) pass of the cyclic
-    # collector over them takes ~150 ms and one falls inside a 10-step window (measured: scratch/ft_steps.py).
-    # Park what exists now in the permanent generation, as long-running training loops do.
-    import gc
-    gc.collect()
-    gc.freeze()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        c = ft.finetune_step(net, crit, x, opt, a.quality, [0.75], fused=not a.two_pass)
-    sync()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
-
-    # phase split on rank 0 (events on the current stream; the plans join it on entry and exit)
-    def timed(fn):
-        torch.cuda.synchronize(dev)
-        t = time.perf_counter()
-        r = fn()
-        torch.cuda.synchronize(dev)
-        return r, (time.perf_counter() - t) * 1e3
-    with torch.no_grad():
-        ck, t_ck = timed(lambda: net.ExtractChekpointRepr(x, quality=0.75, rc=False))
-    opt.zero_grad()
-    if a.two_pass:
-        out, t_fwd = timed(lambda: net.forward_single_quality(x, quality=a.quality, training=True, checkpoint_ref=ck))
-    else:
-        t_ck = 0.0
-        out, t_fwd = timed(lambda: net.forward_finetune(x, a.quality))
-    loss = crit(out, x)["loss"]
-    _, t_bwd = timed(loss.backward)
-    _, t_ar = timed(lambda: sharding.all_reduce_gradients(p for p in net.parameters() if p.requires_grad))
-    _, t_opt = timed(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0), opt.step()))
+    from vampic import sharding
+    forced = dist is None and sharding.init_single_rank_group(dev)     # VAMPIC_FORCE_COLLECTIVES=1: a 1-rank RCCL group
+    if forced:
+        import torch.distributed as dist
+    rec = measure(dev, rank, world, dist, a.batch, a.size, a.steps, a.warmup, a.quality, a.no_graph, a.two_pass, forced)
     if rank == 0:
-        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
-        print(json.dumps({"metric": "REM fine-tune images/sec (256x256 patches, rate loss, Adam)",
-                          "value": round(world * a.batch * a.steps / dt, 2), "unit": "images/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic",
-                          "config": {"workload": f"REM fine-tune step q={a.quality}, check level 0.75, {a.batch}x3x{a.size}x{a.size} per GPU",
-                                     "global_batch": a.batch * world, "trainable_params": n_par,
-                                     "grad_bucket_bytes": 4 * n_par, "hip_graph": not a.no_graph, "fused_checkpoint": not a.two_pass,
-                                     "loss": round(float(c["loss"].detach()), 5)},
-                          "phase_ms": {"checkpoint_forward": round(t_ck, 3), "train_forward": round(t_fwd, 3),
-                                       "backward": round(t_bwd, 3), "grad_all_reduce": round(t_ar, 3),
-                                       "clip_adam": round(t_opt, 3)}}), flush=True)
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,6 +28,86 @@ import torch  # noqa: E402
 FWD_GFLOP_PER_IMAGE_256 = 138.14          # SURVEY 8d, forward([0, 10]) on one 256x256 image
 
 
+def measure(dev, rank=0, world=1, dist=None, batch=32, size=256, steps=5, warmup=2, no_graph=False, foreach_adam=False,
+            forced=False, freeze_gc=True):
+    """Time ``steps`` first_train steps on this rank's synthetic shard; returns the record rank 0 prints (bench.py embeds
+    it in its own line as ``train.first_train``).  ``freeze_gc``: see the comment at gc.freeze() below — the un-frozen
+    time is reported beside it as ``ms_per_step_gc_unfrozen`` (measured first, same steps)."""
+    import vampic
+    from vampic import finetune as ft, sharding
+    from vampic.checkpoint import configure_optimizers
+    args = argparse.Namespace(model="pic", N=192, M=640, multiple_decoder=True, multiple_encoder=True,
+                              multiple_hyperprior=True, dim_chunk=32, division_dimension=[320, 640],
+                              mask_policy="point-based-std", support_progressive_slices=5, delta_encode=True,
+                              total_mu_rep=True, all_scalable=True, learning_rate=1e-4, aux_learning_rate=1e-3,
+                              training_type="first_train")
+    net = vampic.get_model(args, "cpu")
+    torch.nn.Module.load_state_dict(net, vampic.synth.synth_state_dict(net.state_dict(), seed=0))
+    net = net.to(dev).train()
+    ft.first_train_setup(net)
+    net.use_graph = not no_graph
+    args.fused_adam = not foreach_adam
+    opt, _ = configure_optimizers(net, args)
+    crit = ft.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device=dev)
+    x = vampic.synth.synth_image(batch, size, size, seed=300 + rank).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(warmup, 1)):
+        c = ft.first_train_step(net, crit, x, opt, [0, 10])
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = ft.first_train_step(net, crit, x, opt, [0, 10])
+    sync()
+    dt_unfrozen = time.perf_counter() - t0
+    # The plans hold ~1e6 long-lived Python objects (problem structs, views): a full (generation-2) pass of the cyclic
+    # collector over them takes ~150 ms and one can fall inside a short window (measured: scratch/ft_steps.py).  The
+    # headline is measured with what exists now parked in the permanent generation, as long-running training loops do;
+    # the same steps WITHOUT the freeze were timed just above and are reported beside it.
+    import gc
+    if freeze_gc:
+        gc.collect()
+        gc.freeze()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = ft.first_train_step(net, crit, x, opt, [0, 10])
+    sync()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(dev)
+        return r, (time.perf_counter() - t) * 1e3
+    opt.zero_grad()
+    out, t_fwd = timed(lambda: net(x, quality=[0, 10], training=True))
+    loss = crit(out, x)["loss"]
+    _, t_bwd = timed(loss.backward)                         # includes the bucketed all-reduce when world > 1
+    _, t_opt = timed(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0), opt.step()))
+    plan = next(p for k, p in net._plans.items() if k[0] == "full_train")
+    n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    gc.unfreeze()
+    gflop = 3.0 * FWD_GFLOP_PER_IMAGE_256 * (size * size / 65536.0) * batch
+    return ({"metric": "first_train images/sec (256x256 patches, forward [0,10] + backward of 150 M parameters + Adam)",
+                          "value": round(world * batch * steps / dt, 2), "unit": "images/s", "n_gpus": world,
+                          "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_gc_unfrozen": round(dt_unfrozen / steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 split operands, forward, data and weight gradients)",
+                          "data": "synthetic", "collectives": ("forced (1-rank nccl group)" if forced else ("nccl" if world > 1 else "none")),
+                          "config": {"workload": f"first_train step, quality [0, 10], {batch}x3x{size}x{size} per GPU",
+                                     "global_batch": batch * world, "trainable_params": n_par, "grad_bytes": 4 * n_par,
+                                     "grad_buckets": len(plan.bucket_bounds), "hip_graph": not no_graph, "adam": "torch fused" if args.fused_adam else "torch foreach",
+                                     "loss": round(float(c["loss"].detach()), 5)},
+                          "algorithmic_tflops": round(gflop / (dt / steps) / 1e3, 2),
+                          "phase_ms": {"train_forward": round(t_fwd, 3), "backward_incl_all_reduce": round(t_bwd, 3),
+                                       "clip_adam": round(t_opt, 3)}})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,72 +137,13 @@ def main():
     assert world == a.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    import vampic
-    from vampic import finetune as ft, sharding
-    from vampic.checkpoint import configure_optimizers
-    args = argparse.Namespace(model="pic", N=192, M=640, multiple_decoder=True, multiple_encoder=True,
-                              multiple_hyperprior=True, dim_chunk=32, division_dimension=[320, 640],
-                              mask_policy="point-based-std", support_progressive_slices=5, delta_encode=True,
-                              total_mu_rep=True, all_scalable=True, learning_rate=1e-4, aux_learning_rate=1e-3,
-                              training_type="first_train")
-    net = vampic.get_model(args, "cpu")
-    torch.nn.Module.load_state_dict(net, vampic.synth.synth_state_dict(net.state_dict(), seed=0))
-    net = net.to(dev).train()
-    ft.first_train_setup(net)
-    net.use_graph = not a.no_graph
-    args.fused_adam = not a.foreach_adam
-    opt, _ = configure_optimizers(net, args)
-    crit = ft.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device=dev)
-    x = vampic.synth.synth_image(a.batch, a.size, a.size, seed=300 + rank).to(dev)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(max(a.warmup, 1)):
-        c = ft.first_train_step(net, crit, x, opt, [0, 10])
-    sync()
-    # The plans hold ~1e6 long-lived Python objects (problem structs, views): a full (generation-2) pass of the cyclic
-    # collector over them takes ~150 ms and one falls inside a 10-step window (measured: scratch/ft_steps.py).
-    # Park what exists now in the permanent generation, as long-running training loops do.
-    import gc
-    gc.collect()
-    gc.freeze()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        c = ft.first_train_step(net, crit, x, opt, [0, 10])
-    sync()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
-
-    def timed(fn):
-        torch.cuda.synchronize(dev)
-        t = time.perf_counter()
-        r = fn()
-        torch.cuda.synchronize(dev)
-        return r, (time.perf_counter() - t) * 1e3
-    opt.zero_grad()
-    out, t_fwd = timed(lambda: net(x, quality=[0, 10], training=True))
-    loss = crit(out, x)["loss"]
-    _, t_bwd = timed(loss.backward)                         # includes the bucketed all-reduce when world > 1
-    _, t_opt = timed(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0), opt.step()))
+    from vampic import sharding
+    forced = dist is None and sharding.init_single_rank_group(dev)     # VAMPIC_FORCE_COLLECTIVES=1: a 1-rank RCCL group
+    if forced:
+        import torch.distributed as dist
+    rec = measure(dev, rank, world, dist, a.batch, a.size, a.steps, a.warmup, a.no_graph, a.foreach_adam, forced)
     if rank == 0:
-        plan = next(p for k, p in net._plans.items() if k[0] == "full_train")
-        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
-        gflop = 3.0 * FWD_GFLOP_PER_IMAGE_256 * (a.size * a.size / 65536.0) * a.batch
-        print(json.dumps({"metric": "first_train images/sec (256x256 patches, forward [0,10] + backward of 150 M parameters + Adam)",
-                          "value": round(world * a.batch * a.steps / dt, 2), "unit": "images/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (bf16x3 split operands, forward, data and weight gradients)",
-                          "data": "synthetic",
-                          "config": {"workload": f"first_train step, quality [0, 10], {a.batch}x3x{a.size}x{a.size} per GPU",
-                                     "global_batch": a.batch * world, "trainable_params": n_par, "grad_bytes": 4 * n_par,
-                                     "grad_buckets": len(plan.bucket_bounds), "hip_graph": not a.no_graph, "adam": "torch fused" if args.fused_adam else "torch foreach",
-                                     "loss": round(float(c["loss"].detach()), 5)},
-                          "algorithmic_tflops": round(gflop / (dt / a.steps) / 1e3, 2),
-                          "phase_ms": {"train_forward": round(t_fwd, 3), "backward_incl_all_reduce": round(t_bwd, 3),
-                                       "clip_adam": round(t_opt, 3)}}), flush=True)
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -232,3 +232,44 @@ def test_bucketed_gradient_exchange_two_ranks(tmp_path):
     for g0, g1, m in zip(r0["grads"], r1["grads"], mean):
         assert g0 == g1                                              # bit-identical on both ranks
         assert torch.allclose(torch.tensor(g0), m * scale, rtol=1e-5, atol=1e-7)
+
+
+def _forced_worker(port, path):
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert not sharding.collectives_active()
+    assert not sharding.init_single_rank_group(None, "gloo")          # flag not set: nothing happens
+    os.environ["VAMPIC_FORCE_COLLECTIVES"] = "1"
+    assert sharding.init_single_rank_group(None, "gloo") and dist.get_world_size() == 1
+    assert sharding.collectives_active()
+    flat = torch.arange(24, dtype=torch.float32)
+    want = flat.clone()
+    red = sharding.BucketReducer()
+    red(0, flat[:16])
+    red(1, flat[16:])
+    n_pending = len(red.pending)
+    red.finish()
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.tensor([1.0, 2.0, 3.0])
+    nbytes = sharding.all_reduce_gradients([p])
+    os.environ["VAMPIC_FORCE_COLLECTIVES"] = "0"
+    off = sharding.collectives_active()
+    with open(path, "w") as f:
+        json.dump({"pending": n_pending, "same": bool(torch.equal(flat, want)), "log": red.log, "nbytes": nbytes,
+                   "grad": p.grad.tolist(), "max": sharding.max_over_ranks(2.5), "off": off}, f)
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one(tmp_path):
+    """VAMPIC_FORCE_COLLECTIVES=1: a 1-rank group issues every exchange step (what the one-GPU box runs over RCCL,
+    tests/test_gpu_collectives.py); the values are unchanged (sums over one rank), and without the flag a 1-rank group
+    stays silent."""
+    import json
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "forced.json")
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), path))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    r = json.load(open(path))
+    assert r == {"pending": 2, "same": True, "log": [[0, 16], [1, 8]], "nbytes": 16, "grad": [1.0, 2.0, 3.0], "max": 2.5, "off": False}
