@@ -19,6 +19,7 @@ ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQR
 # enum vam_conv_flags
 CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW, CONV_IN_BF3, CONV_OUT_BF3 = 1, 2, 4, 8, 16
 CONV_W_BF16, CONV_IN_BF16, CONV_OUT_BF16, CONV_AUX_BF16 = 32, 64, 128, 256      # bf16-storage mode (BASELINE configs[2])
+CONV_MUL_GELU_GRAD = 512         # training: the mul operand is a GELU's pre-activation z, the result is multiplied by gelu'(z)
 # enum vam_pack_mode
 PACK_CONV, PACK_DECONV5S2, PACK_PS2, PACK_GDN, PACK_CONV_DGRAD, PACK_GDN_T = range(6)
 # enum vam_ew_op
@@ -76,6 +77,7 @@ class VamConv(C.Structure):
         ("flags", C.c_int32),
         ("pre", VamAux), ("mul", VamAux), ("post", VamAux), ("post2", VamAux),
         ("in_amax", C.c_void_p * VAM_MAX_SEG), ("out_amax", C.c_void_p),
+        ("preact", VamAux),
     ]
 
 

@@ -79,4 +79,11 @@ __device__ __forceinline__ float vam_gelu(float v) {
   return (v * 0.5f) * (1.0f + r);
 }
 
+// d/dv [ v Phi(v) ] = Phi(v) + v phi(v): the derivative of nn.GELU() (autograd of pic.py:86 / layers/layers.py:35-41).
+// One definition for the element-wise backward kernel (train_gs.hip) and the data-gradient launches that apply it in
+// their epilogue (VAM_CONV_MUL_GELU_GRAD): the two routes give the same bits.
+__device__ __forceinline__ float vam_gelu_grad(float v) {
+  return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+}
+
 }  // namespace vam

@@ -61,6 +61,8 @@ struct ConvP {
   const float* post;
   const float* post2;
   int ld_pre, ld_mul, ld_post, ld_post2;
+  float* preact;        // optional second output: the value the activation is applied to (bias + pre + conv), fp32, indexed like the output
+  int ld_preact;
   int tiles_n;
   const int* in_amax[VAM_MAX_SEG];   // MODE 3: per input segment, a device cell holding the bits of an upper bound of max |x| (nullptr: unused)
   int* out_amax;        // any mode: if set, the epilogue folds max |stored value| into this cell (integer atomicMax on the float's bits)
@@ -922,6 +924,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   const bool out_p3 = (P.flags & VAM_CONV_OUT_BF3) != 0;     // host guarantees: split mode, vec_ok, no PS2
   const bool out16 = (P.flags & VAM_CONV_OUT_BF16) != 0;     // bf16 NHWC output (ldo counts bf16 elements); host guarantees vec_ok
   const bool aux16 = (P.flags & VAM_CONV_AUX_BF16) != 0;     // pre / mul / post / post2 are bf16 NHWC tensors
+  const bool mulg = (P.flags & VAM_CONV_MUL_GELU_GRAD) != 0; // the mul operand is a GELU's pre-activation z: multiply by gelu'(z)
   auto ld_aux = [&](const float* base, size_t off) -> float4 {   // four consecutive channels of an epilogue operand
     if (aux16) {
       const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
@@ -987,10 +990,12 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         const float4 t4 = ld_aux(P.pre, opix * P.ld_pre + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
+      if (P.preact) *reinterpret_cast<float4*>(P.preact + opix * P.ld_preact + cch) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
       if (P.mul) {
-        const float4 t4 = ld_aux(P.mul, opix * P.ld_mul + cch);
+        float4 t4 = ld_aux(P.mul, opix * P.ld_mul + cch);
+        if (mulg) t4 = make_float4(vam_gelu_grad(t4.x), vam_gelu_grad(t4.y), vam_gelu_grad(t4.z), vam_gelu_grad(t4.w));
         v[0] *= t4.x; v[1] *= t4.y; v[2] *= t4.z; v[3] *= t4.w;
       }
       if (P.post) {
@@ -1039,8 +1044,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         }
         float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
         if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
+        if (P.preact) P.preact[opix * P.ld_preact + cch] = x;
         x = apply_act(x, P.act);
-        if (P.mul) x = x * P.mul[opix * P.ld_mul + cch];
+        if (P.mul) x = x * (mulg ? vam_gelu_grad(P.mul[opix * P.ld_mul + cch]) : P.mul[opix * P.ld_mul + cch]);
         if (P.post) x = x + P.post[opix * P.ld_post + cch];
         if (P.post2) x = x + P.post2[opix * P.ld_post2 + cch];
         if (pub) omax = fmaxf(omax, fabsf(x));
@@ -1094,6 +1100,8 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const unsigned u_ldo = (unsigned)__builtin_amdgcn_readfirstlane(P.ldo), u_ldpre = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_pre);
     const unsigned u_ldmul = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_mul), u_ldpost = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post);
     const unsigned u_ldpost2 = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post2);
+    const __amdgpu_buffer_rsrc_t r_preact = desc(P.preact);
+    const unsigned u_ldpreact = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_preact);
     const int u_act = __builtin_amdgcn_readfirstlane(P.act);
     const bool full_rows = m0 + BM <= P.P;
 #pragma unroll
@@ -1141,12 +1149,21 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += t[r];
           }
+          if (P.preact) {
+            const unsigned c4 = (poff * u_ldpreact + cch) << 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_preact, off(r, u_ldpreact, c4), 0, 0);
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], u_act);
           if (P.mul) {
             const unsigned c4 = (poff * u_ldmul + cch) << 2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_mul, off(r, u_ldmul, c4), 0, 0));
+            if (mulg) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) t[r] = vam_gelu_grad(t[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] *= t[r];
           }
@@ -1688,7 +1705,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
     p.wpack = c.wpack; p.bias = c.bias; p.out = c.out;
     p.ldo = c.ldo; p.Hf = c.Hf; p.Wf = c.Wf; p.osy = c.osy; p.osx = c.osx; p.ooy = c.ooy; p.oox = c.oox;
     constexpr int PUBLIC_FLAGS = VAM_CONV_SQUARE_IN | VAM_CONV_PS2 | VAM_CONV_OUT_NCHW | VAM_CONV_IN_BF3 | VAM_CONV_OUT_BF3 |
-                                 VAM_CONV_W_BF16 | VAM_CONV_IN_BF16 | VAM_CONV_OUT_BF16 | VAM_CONV_AUX_BF16;
+                                 VAM_CONV_W_BF16 | VAM_CONV_IN_BF16 | VAM_CONV_OUT_BF16 | VAM_CONV_AUX_BF16 | VAM_CONV_MUL_GELU_GRAD;
     VAM_REQUIRE((c.flags & ~PUBLIC_FLAGS) == 0, "conv[%d]: unknown flag bits 0x%x", i, c.flags & ~PUBLIC_FLAGS);
     p.Cq = c.Cq; p.act = c.act; p.flags = c.flags & PUBLIC_FLAGS;      // bits 29 / 30 are the kernel's own
     // 16-channel multi-tap problems: vam_pack_conv_weights lays the weights out two taps per 32-channel chunk in the
@@ -1709,9 +1726,15 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
       const double out_pix = (double)c.B * c.Hf * c.Wf;
       auto fits = [&](const void* q, int ld) { return !q || (ld < (1 << 24) && out_pix * ld * 4.0 < 2147483648.0); };
       if (!(out_pix < (double)(1 << 22) && fits(c.out, c.ldo) && fits(c.pre.ptr, c.pre.ld) && fits(c.mul.ptr, c.mul.ld) &&
-            fits(c.post.ptr, c.post.ld) && fits(c.post2.ptr, c.post2.ld)))
+            fits(c.post.ptr, c.post.ld) && fits(c.post2.ptr, c.post2.ld) && fits(c.preact.ptr, c.preact.ld)))
         p.flags |= VAM_CONVI_STAGED;
     }
+    VAM_REQUIRE(!(c.flags & VAM_CONV_MUL_GELU_GRAD) || (c.mul.ptr && !(c.flags & VAM_CONV_AUX_BF16)),
+                "conv[%d]: VAM_CONV_MUL_GELU_GRAD needs an fp32 mul operand (the GELU's pre-activation)", i);
+    VAM_REQUIRE(!c.preact.ptr || (!(c.flags & (VAM_CONV_OUT_NCHW | VAM_CONV_W_BF16)) && c.preact.ld % 4 == 0 &&
+                                  (((uintptr_t)c.preact.ptr) & 15) == 0 && c.preact.ld >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N)),
+                "conv[%d]: preact is an fp32 NHWC tensor indexed like the output (16-byte aligned, ld %% 4 == 0, ld >= channels)", i);
+    p.preact = const_cast<float*>(c.preact.ptr); p.ld_preact = c.preact.ld;
     p.pre = c.pre.ptr; p.ld_pre = c.pre.ld;
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;

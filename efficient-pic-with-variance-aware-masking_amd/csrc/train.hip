@@ -387,6 +387,11 @@ __global__ void gauss_train_kernel(const LikArgs a) {
   }
 }
 
+// LDS-tiled kernel for the k3 / k5 layers (wgrad_lds.hip)
+bool wgrad2_eligible(const vam_wgrad& p);
+int wgrad2_splits(const vam_wgrad& p);
+int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream);
+
 static inline unsigned sgrid(long n, int block) {
   long g = (n + block - 1) / block;
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -414,6 +419,7 @@ static void wgrad_tile(const vam_wgrad& p, int* tn, int* tc) {
 }
 
 static int wgrad_splits(const vam_wgrad& p) {
+  if (wgrad2_eligible(p)) return wgrad2_splits(p);
   // enough blocks to fill the chip (4 blocks of 8 waves per CU x 256 CUs, twice over), at least 2048 pixels per split
   int tn, tc;
   wgrad_tile(p, &tn, &tc);
@@ -471,6 +477,18 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
   // input segments are the 320-channel hyper-latents and 32 ... 160 channels of y_hat, so the 320-channel problem ran
   // on the smallest tile too.)
   bool done[VAM_MAX_WGRAD_GROUP] = {};
+  // k3 / k5 problems on the supported grids: the LDS-tiled kernel, one launch per (kernel size, stride) class
+  for (int i0 = 0; i0 < n_probs; ++i0) {
+    if (done[i0] || !use_split || !wgrad2_eligible(probs[i0])) continue;
+    vam_wgrad cls[VAM_MAX_WGRAD_GROUP];
+    int n_cls = 0;
+    for (int i = i0; i < n_probs; ++i) {
+      if (done[i] || !wgrad2_eligible(probs[i]) || probs[i].kh != probs[i0].kh || (probs[i].stride == 2) != (probs[i0].stride == 2)) continue;
+      done[i] = true;
+      cls[n_cls++] = probs[i];
+    }
+    if (int rc = wgrad2_launch_class(cls, n_cls, (hipStream_t)stream)) return rc;
+  }
   for (int i0 = 0; i0 < n_probs; ++i0) {
     if (done[i0]) continue;
     const int tn = tns[i0], tc = tcs[i0];

@@ -23,9 +23,7 @@ struct EwArgs {
 
 __device__ __forceinline__ float gelu_f(float v) { return vam_gelu(v); }
 // d/dv [ v * Phi(v) ] = Phi(v) + v * phi(v)
-__device__ __forceinline__ float gelu_d(float v) {
-  return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
-}
+__device__ __forceinline__ float gelu_d(float v) { return vam_gelu_grad(v); }
 
 enum { EW_GELU_FWD = 0, EW_GELU_BWD, EW_GATE_BWD, EW_GDN_APPLY, EW_GDN_BWD_PREP, EW_GDN_BWD_FIN, EW_CLAMP_BWD, EW_AXPY, EW_GATE_FWD,
        EW_REPARAM_BWD, EW_HTANH_FWD, EW_HTANH_BWD, EW_MASK_SPLIT };

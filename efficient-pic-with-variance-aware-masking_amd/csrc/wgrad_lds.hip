@@ -1,0 +1,338 @@
+// Weight gradients of the k3 / k5 convolutions, LDS-tiled (round 4; first-stage training, BASELINE configs[3]:
+// autograd of F.conv2d in the reference's training/step.py:32-135).
+//
+//   dW[n][c_off + c][ty][tx] = sum_p dY[p][n] * X[pix(p) * stride + (ty - pad, tx - pad)][c]
+//
+// is a GEMM whose K axis is the PIXEL axis, so the matrix pipe wants, per lane, 8 consecutive pixels of one channel —
+// the transpose of how NHWC tensors lie in memory.  wgrad_kernel (train.hip) gathers them with 8 dword loads per fragment
+// and re-splits every fp32 value into its bf16x3 planes in registers, per wave, per tile and PER TAP: ~45 vector
+// instructions per fragment pace the loop (r03: 65 ms of a 160 ms step).  Here a workgroup owns a 128 (n) x 64 (c) tile of
+// ONE kernel row ty with all kw taps, and walks its pixel range in chunks of 64 output pixels:
+//   * the chunk of dY (64 pixels x 128 channels) and the input rows the kernel row touches ((SEGW - 1) stride + kw pixels
+//     per image row x 64 channels) are loaded ONCE with coalesced 16-byte loads, split exactly into hi / mid / lo bf16
+//     planes (truncation split, as conv_igemm_kernel) and stored in LDS as [32-channel block][plane][pixel][32 bf16];
+//   * operand fragments come out of LDS already transposed: ds_read_b64_tr_b16 hands lane (channel i, pixel group) four
+//     consecutive pixels of its channel (64-byte pixel rows: four rows x 64 B = all 64 banks, conflict-free); a tap is a
+//     pixel-row offset of the same image, so the kw taps share one staged tile (stride 2: even and odd input columns are
+//     kept apart so that a tap's pixels stay consecutive);
+//   * each of the 8 waves owns one 32 x 32 block of the tile for all kw taps: per 16-pixel step one dY fragment and kw
+//     input fragments feed 6 kw MFMAs (v_mfma_f32_32x32x16_bf16; the six partial products of weight <= 2, smallest first).
+// Every element is split once per (tile, kernel row) instead of once per (wave tile, tap), and the loop's vector work is
+// what the loader does between two barriers.  Products are exact; the accumulation order is fixed (pixel chunks in order,
+// pixel splits reduced in split order by wgrad_reduce_kernel): deterministic, no float atomics.
+#include "common.h"
+
+namespace vam {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Wgrad2Args {
+  vam_wgrad p[VAM_MAX_WGRAD_GROUP];
+};
+
+constexpr int W2_NB = 128, W2_CB = 64, W2_KP = 64, W2_NT = 512;
+constexpr int W2_SY_BYTES = (W2_NB / 32) * 3 * W2_KP * 64;            // 49,152
+
+// LDS pixels of the input tile: R image rows of XWL pixel slots each (stride 2: even columns, then odd columns)
+__host__ __device__ constexpr int w2_xw(int segw, int kw, int stride) { return (segw - 1) * stride + kw; }
+__host__ __device__ constexpr int w2_xwl(int segw, int kw, int stride) {
+  return stride == 2 ? 2 * ((w2_xw(segw, kw, stride) + 1) / 2) : w2_xw(segw, kw, stride);
+}
+__host__ __device__ constexpr int w2_xp_max(int kw, int stride) {      // over SEGW in {16 (R = 4), 32 (R = 2), 64 (R = 1)}
+  const int a = 4 * w2_xwl(16, kw, stride), b = 2 * w2_xwl(32, kw, stride), c = w2_xwl(64, kw, stride);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+__device__ __forceinline__ void w2_split4(const u32x4 v, uint2 (&pl)[3]) {
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float f = __uint_as_float(v[e]);
+    hb[e] = v[e];
+    const float r1 = f - __uint_as_float(hb[e] & 0xFFFF0000u);
+    mb[e] = __float_as_uint(r1);
+    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e] & 0xFFFF0000u));
+  }
+  pl[0] = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+  pl[1] = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+  pl[2] = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+}
+
+template <int KW, int STRIDE>
+__global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int XP_MAX = w2_xp_max(KW, STRIDE);
+  constexpr int NXU = (XP_MAX * 16 + W2_NT - 1) / W2_NT;      // 16-byte units of the input tile per thread
+  constexpr int PAD = KW / 2;
+  unsigned char* sY = smem;
+  unsigned char* sX = smem + W2_SY_BYTES;
+  const vam_wgrad& pr = args.p[blockIdx.y];
+  const int N = pr.N, C = pr.C;
+  const int n_tiles = (N + W2_NB - 1) / W2_NB, c_tiles = (C + W2_CB - 1) / W2_CB;
+  const int per = KW * n_tiles * c_tiles;
+  const int S = pr.splits > 1 ? pr.splits : 1;
+  int bid = blockIdx.x;
+  if (bid >= per * S) return;                                   // whole block leaves: no barrier is skipped by a part of it
+  const int split = bid / per;
+  bid -= split * per;
+  const int ty = bid % KW;
+  bid /= KW;
+  const int n0 = (bid % n_tiles) * W2_NB, c0 = (bid / n_tiles) * W2_CB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int H = pr.H, W = pr.W, HW = H * W;
+  const int Hx = STRIDE == 2 ? pr.Hx : H, Wx = STRIDE == 2 ? pr.Wx : W;
+  const int SEGW = W < 64 ? W : 64;                             // host: W in {16, 32} or a multiple of 64; H * W % 64 == 0
+  const int lg = SEGW == 64 ? 6 : (SEGW == 32 ? 5 : 4);
+  const int R = 64 >> lg;
+  const int XW = (SEGW - 1) * STRIDE + KW;
+  const int XWH = (XW + 1) >> 1;
+  const int XWL = STRIDE == 2 ? 2 * XWH : XW;
+  const int XPL = R * XWL;                                      // LDS pixel slots per (channel block, plane)
+  const int n_chunks = (int)(((long)pr.B * HW) >> 6);
+  const int chunks_per = (n_chunks + S - 1) / S;
+  const int q_begin = split * chunks_per;
+  const int q_end = q_begin + chunks_per < n_chunks ? q_begin + chunks_per : n_chunks;
+
+  auto desc = [](const void* q) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)), 0, 0x7FFFFFFF, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_dy = desc(pr.dy), r_x = desc(pr.x);
+  const unsigned OOB = 0x80000000u;
+
+  // ---- staging roles (fixed per thread over all chunks)
+  // dY: unit u = tid + 512 i -> pixel tid / 32 + 16 i, channels 4 (tid % 32) .. + 3 of the tile
+  const int ycc = (tid & 31) * 4;                               // channel inside the 128-channel tile
+  const bool y_ok = n0 + ycc < N;                               // (host: N % 4 == 0)
+  const unsigned y_src = (unsigned)(((tid >> 5) * pr.ld_dy + n0 + ycc) << 2);         // + (p0 + 16 i) * ld_dy * 4
+  const unsigned y_dst = (unsigned)(((ycc >> 5) * 3 * W2_KP + (tid >> 5)) * 64 + (ycc & 31) * 2);   // + plane * 64 * 64 + 16 i * 64
+  // X: unit u = tid + 512 i -> tile pixel tid / 16 + 32 i, channels 4 (tid % 16) .. + 3
+  const int xcc = (tid & 15) * 4;
+  const bool xc_ok = c0 + xcc < C;                              // (host: C % 4 == 0)
+  int x_r[NXU], x_j[NXU];
+  unsigned x_dst[NXU];
+#pragma unroll
+  for (int i = 0; i < NXU; ++i) {
+    const int xp = (tid >> 4) + 32 * i;                         // pixel of the tile in raster order: row r, column j
+    const int r = xp / XW, j = xp - r * XW;
+    x_r[i] = xp < R * XW ? r : -1;
+    x_j[i] = j;
+    const int lp = r * XWL + (STRIDE == 2 ? (j & 1) * XWH + (j >> 1) : j);
+    x_dst[i] = (unsigned)(((xcc >> 5) * 3 * XPL + lp) * 64 + (xcc & 31) * 2);          // + plane * XPL * 64
+  }
+
+  u32x4 ry[4], rx[NXU];
+  auto issue = [&](int q) {
+    const int p0 = q << 6;
+    const int b = p0 / HW;
+    const int rem = p0 - b * HW;
+    const int oy0 = rem / W, ox0 = rem - oy0 * W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned o = y_src + (unsigned)((p0 + 16 * i) * pr.ld_dy) * 4u;
+      ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, (int)(y_ok ? o : OOB), 0, 0));
+    }
+    const int ix0 = ox0 * STRIDE - PAD;
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+      const int iy = (oy0 + x_r[i]) * STRIDE - PAD + ty, ix = ix0 + x_j[i];
+      const bool ok = xc_ok && x_r[i] >= 0 && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx;
+      const unsigned o = (unsigned)(((b * Hx + iy) * Wx + ix) * pr.ld_x + c0 + xcc) << 2;
+      rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(ok ? o : OOB), 0, 0));
+    }
+  };
+  const bool want_db = pr.db != nullptr && ty == 0 && c0 == 0 && pr.c_off == 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 pl[3];
+      w2_split4(ry[i], pl);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sY + y_dst + k * (W2_KP * 64) + i * (16 * 64)) = pl[k];
+      if (want_db) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[e] += __uint_as_float(ry[i][e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+      if (x_r[i] >= 0) {
+        uint2 pl[3];
+        w2_split4(rx[i], pl);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sX + x_dst[i] + k * (XPL * 64)) = pl[k];
+      }
+    }
+  };
+
+  // ---- compute roles: wave = one 32 x 32 block of the tile, all KW taps
+  const int nb = wid & 3, cb = wid >> 2;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  // transposed read: lane 4 q + p of 16-lane group g supplies pixel row q, channels 16 (g & 1) + 4 p .. + 3; the group
+  // receives pixels 8 (g >> 1) + 4 h + {0..3} of channel 16 (g & 1) + (lane & 15)
+  const unsigned lane_off = (unsigned)((8 * (g >> 1) + qq) * 64 + (16 * (g & 1) + 4 * pp) * 2);
+  const unsigned a_base = lane_off + (unsigned)(nb * 3 * W2_KP * 64);
+  const unsigned b_base = lane_off + (unsigned)(cb * 3 * XPL * 64);
+  f32x16 acc[KW];
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto tr8 = [&](const unsigned char* base, unsigned off) -> bf16x8 {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + 4 * 64));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r = (ks * 16) >> lg, oxs = (ks * 16) & (SEGW - 1);
+      bf16x8 fa[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fa[k] = tr8(sY, a_base + (unsigned)((k * W2_KP + ks * 16) * 64));
+      const unsigned row = (unsigned)(r * XWL + oxs);
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const unsigned px = row + (STRIDE == 2 ? (unsigned)((t & 1) * XWH + (t >> 1)) : (unsigned)t);
+        bf16x8 fb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fb[k] = tr8(sX, b_base + (unsigned)(k * XPL * 64) + px * 64u);
+        // smallest terms first, as in the convolution kernel: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  // LDS slots the loader never writes must read as zero: pixel slots of the de-interleaved rows beyond XW
+  if (STRIDE == 2) {
+    for (int i = tid; i < 2 * 3 * XPL * 4; i += W2_NT) reinterpret_cast<uint4*>(sX)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
+  if (q_begin < q_end) {
+    issue(q_begin);
+    stage();
+    __syncthreads();
+    for (int q = q_begin; q < q_end; ++q) {
+      const bool more = q + 1 < q_end;                          // block-uniform
+      if (more) issue(q + 1);                                   // in flight under the MFMAs
+      compute();
+      __syncthreads();                                          // every wave has read this chunk
+      if (more) stage();
+      __syncthreads();
+    }
+  }
+
+  // ---- results: dW (or this split's partial tile), db
+  const int taps = KW * KW;
+  float* part = S > 1 ? pr.workspace + (size_t)split * ((size_t)N * C * taps + N) : nullptr;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int c = c0 + 32 * cb + l31;
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int tap = ty * KW + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < N && c < C) {
+        if (part) part[((size_t)n * C + c) * taps + tap] = acc[t][r];
+        else pr.dw[((size_t)n * pr.cin_total + pr.c_off + c) * taps + tap] = acc[t][r];
+      }
+    }
+  }
+  if (want_db) {                                                // block-uniform
+    float* red = reinterpret_cast<float*>(smem);                // [16 pixel groups][128 channels]; the tiles are dead
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(tid >> 5) * W2_NB + ycc + e] = bs[e];
+    __syncthreads();
+    if (tid < W2_NB && n0 + tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k * W2_NB + tid];
+      if (part) part[(size_t)N * C * taps + n0 + tid] = t;
+      else pr.db[n0 + tid] = t;
+    }
+  }
+}
+
+static size_t w2_lds_bytes(int kw, int stride) { return (size_t)W2_SY_BYTES + (size_t)2 * 3 * w2_xp_max(kw, stride) * 64; }
+
+// ---------------------------------------------------------------------------------------------------- host side
+// A problem takes this kernel when its geometry is the one the chunking assumes; everything else (1x1 layers, the small
+// grids of the hyperprior, odd channel counts) stays with wgrad_kernel.
+bool wgrad2_eligible(const vam_wgrad& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VAMPIC_WGRAD_LDS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on) return false;
+  if (!((p.kh == 3 || p.kh == 5) && p.kw == p.kh)) return false;
+  const int stride = p.stride == 2 ? 2 : 1;
+  if (!(p.W == 16 || p.W == 32 || (p.W >= 64 && p.W % 64 == 0))) return false;
+  if (((long)p.H * p.W) % 64 != 0) return false;
+  if (p.W < 64 && p.H % (64 / p.W) != 0) return false;
+  if (p.N % 4 || p.C % 4 || p.ld_x % 4 || p.ld_dy % 4) return false;
+  if ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15) return false;
+  const double px = (double)p.B * (stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
+  if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) return false;
+  if (p.C < 16 || p.N < 32) return false;
+  return true;
+}
+
+int wgrad2_splits(const vam_wgrad& p) {
+  // blocks per split: kh * n tiles * c tiles; aim at ~2 blocks per CU over the chip, at least 16 chunks (1024 pixels) per
+  // split — every split writes its partial tile (N C taps floats) and the reduce kernel reads them all back
+  const long per = (long)p.kh * cdiv(p.N, W2_NB) * cdiv(p.C, W2_CB);
+  const long chunks = ((long)p.B * p.H * p.W) >> 6;
+  long s = (512 + per - 1) / per;
+  const long cap = chunks / 16;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  return s < 2 ? 1 : (int)s;
+}
+
+template <int KW, int STRIDE>
+static int w2_launch(const Wgrad2Args& a, int max_blocks, int n_sub, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = w2_lds_bytes(KW, STRIDE);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE>), dim3(max_blocks, n_sub), dim3(W2_NT), lds, s, a);
+  return check_launch("wgrad2_kernel");
+}
+
+// problems of one (kernel size, stride) class, all eligible
+int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
+  Wgrad2Args a;
+  int max_blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    a.p[i] = probs[i];
+    const vam_wgrad& p = probs[i];
+    const int S = p.splits > 1 ? p.splits : 1;
+    const int nb = p.kh * cdiv(p.N, W2_NB) * cdiv(p.C, W2_CB) * S;
+    max_blocks = nb > max_blocks ? nb : max_blocks;
+  }
+  const int kw = probs[0].kh, st = probs[0].stride == 2 ? 2 : 1;
+  if (kw == 3 && st == 1) return w2_launch<3, 1>(a, max_blocks, n, stream);
+  if (kw == 5 && st == 1) return w2_launch<5, 1>(a, max_blocks, n, stream);
+  if (kw == 3 && st == 2) return w2_launch<3, 2>(a, max_blocks, n, stream);
+  return w2_launch<5, 2>(a, max_blocks, n, stream);
+}
+
+}  // namespace vam

@@ -57,7 +57,7 @@ def lower_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs: Se
     cur: List[List[View]] = [list(i) for i in inputs]
     tapes = [dict(stack=stacks[k], x=[], z=[], out=None) for k in range(K)]
     for d in range(depth):
-        probs, zs = [], []
+        probs, zs, nxt = [], [], []
         last = d == depth - 1
         for k in range(K):
             m, act = lay[k][d]
@@ -65,13 +65,18 @@ def lower_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs: Se
             v0 = cur[k][0]
             Ho, Wo, Co = _layer_out(m, v0)
             z = outs[k] if (last and outs[k] is not None) else plan.buf(v0.B, Ho, Wo, Co)
-            probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], z))
+            if last:
+                probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], z))
+            else:                       # GELU in the epilogue (as the eval plans), pre-activation kept as the second output
+                a = plan.buf(v0.B, Ho, Wo, Co)
+                probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], a, L.ACT_GELU, preact=z))
+                nxt.append([a])
             tapes[k]["x"].append(list(cur[k]))
             tapes[k]["z"].append(z)
             zs.append(z)
         plan.conv(probs)
         if not last:
-            cur = [[G._gelu(plan, z)] for z in zs]
+            cur = nxt
         else:
             for k in range(K):
                 tapes[k]["out"] = zs[k]
@@ -105,6 +110,7 @@ def lower_stacks_backward(bw: E.Plan, tapes: Sequence[dict], d_outs: Sequence[Vi
         bw.wgrad(wg)
         if d == 0 and not need_dx:
             return None
+        gz = (lambda k: tapes[k]["z"][d - 1]) if d > 0 else (lambda k: None)     # pre-activation of the GELU in front of layer d
         if not isinstance(m0, Ly.SubpelConv) and m0.stride == 2:
             if m0.kernel_size == 5:                              # transposed convolution: four phase problems per stack
                 das, probs = [], []
@@ -112,7 +118,7 @@ def lower_stacks_backward(bw: E.Plan, tapes: Sequence[dict], d_outs: Sequence[Vi
                     x0 = tapes[k]["x"][d][0]
                     assert len(tapes[k]["x"][d]) == 1
                     o = bw.buf(x0.B, x0.H, x0.W, x0.C)
-                    probs += [ops.conv_problem(p_, [g_conv[k]], o) for p_ in packs[k].d[id(ms[k])]]
+                    probs += [ops.conv_problem(p_, [g_conv[k]], o, gelu_z=gz(k)) for p_ in packs[k].d[id(ms[k])]]
                     das.append(o)
                 bw.conv(probs)
             else:                                                # k3 s2: zero insertion + stride-1 data-gradient problem
@@ -123,13 +129,13 @@ def lower_stacks_backward(bw: E.Plan, tapes: Sequence[dict], d_outs: Sequence[Vi
                     bw.call(lambda s=g_conv[k], u=u: ops.upsample2_zero(s, u), "zero insertion")
                     ups.append(u)
                 das = [bw.buf(u.B, u.H, u.W, sum(v.C for v in tapes[k]["x"][d])) for k, u in enumerate(ups)]
-                bw.conv([ops.conv_problem(packs[k].d[id(ms[k])], [ups[k]], das[k]) for k in range(K)])
+                bw.conv([ops.conv_problem(packs[k].d[id(ms[k])], [ups[k]], das[k], gelu_z=gz(k)) for k in range(K)])
         else:
             das = [bw.buf(g_conv[k].B, g_conv[k].H, g_conv[k].W, sum(v.C for v in tapes[k]["x"][d])) for k in range(K)]
-            bw.conv([ops.conv_problem(packs[k].d[id(ms[k])], [g_conv[k]], das[k]) for k in range(K)])
+            bw.conv([ops.conv_problem(packs[k].d[id(ms[k])], [g_conv[k]], das[k], gelu_z=gz(k)) for k in range(K)])
         if d == 0:
             return das
-        dz = [G._gelu_bwd(bw, tapes[k]["z"][d - 1], das[k]) for k in range(K)]
+        dz = das                          # the data-gradient launches applied gelu'(z) of the GELU in front of the layer
     return None
 
 

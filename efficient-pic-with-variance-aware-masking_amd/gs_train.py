@@ -202,17 +202,15 @@ def _gelu(plan, pre: View) -> View:
 
 
 def _ru_fwd(plan, pk: TransformPacks, ru: Ly.ResidualUnit, x: View, tape: list) -> View:
-    """GELU(conv1x1(GELU(conv3x3(GELU(conv1x1(x))))) + x)   (layers/layers.py:30-48)."""
+    """GELU(conv1x1(GELU(conv3x3(GELU(conv1x1(x))))) + x)   (layers/layers.py:30-48).  Every launch applies its GELU in the
+    epilogue (as the eval plans do) and keeps the pre-activation as a second output (the backward needs gelu'(z))."""
     c1, c2, c3 = ru.conv[0], ru.conv[2], ru.conv[4]
-    h1p = plan.buf(x.B, x.H, x.W, c1.out_channels)
-    plan.conv([ops.conv_problem(pk.f[id(c1)], [x], h1p)])
-    h1 = _gelu(plan, h1p)
-    h2p = plan.buf(x.B, x.H, x.W, c2.out_channels)
-    plan.conv([ops.conv_problem(pk.f[id(c2)], [h1], h2p)])
-    h2 = _gelu(plan, h2p)
-    op = plan.buf(x.B, x.H, x.W, c3.out_channels)
-    plan.conv([ops.conv_problem(pk.f[id(c3)], [h2], op, pre=x)])
-    o = _gelu(plan, op)
+    h1p, h1 = plan.buf(x.B, x.H, x.W, c1.out_channels), plan.buf(x.B, x.H, x.W, c1.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c1)], [x], h1, L.ACT_GELU, preact=h1p)])
+    h2p, h2 = plan.buf(x.B, x.H, x.W, c2.out_channels), plan.buf(x.B, x.H, x.W, c2.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c2)], [h1], h2, L.ACT_GELU, preact=h2p)])
+    op, o = plan.buf(x.B, x.H, x.W, c3.out_channels), plan.buf(x.B, x.H, x.W, c3.out_channels)
+    plan.conv([ops.conv_problem(pk.f[id(c3)], [h2], o, L.ACT_GELU, pre=x, preact=op)])
     tape.append(dict(kind="ru", mod=ru, x=x, h1p=h1p, h1=h1, h2p=h2p, h2=h2, op=op))
     return o
 
@@ -277,12 +275,18 @@ def lower_g_s_train(plan: E.Plan, dec: nn.Sequential, y: View, x_hat: torch.Tens
 
 
 # ============================================================================= backward
-def _conv_bwd(bw, pk, layer, x: View, dy: View, grads, need_dx: bool = True, dx_post: Optional[View] = None) -> Optional[View]:
+def _conv_bwd(bw, pk, layer, x: View, dy: View, grads, need_dx: bool = True, dx_post: Optional[View] = None,
+              gelu_z: Optional[View] = None) -> Optional[View]:
+    """Weight / bias gradient of a stride-1 layer and (``need_dx``) its data gradient + ``dx_post``.  ``gelu_z``: the layer's
+    input was GELU(z) — the data-gradient launch multiplies by gelu'(z) in its epilogue and returns dL/dz."""
     bw.wgrad(ops.wgrad_problems([x], dy, grads[id(layer.weight)], grads[id(layer.bias)]))
     if not need_dx:
         return None
     dx = bw.buf(x.B, x.H, x.W, x.C)
-    bw.conv([ops.conv_problem(pk.d[id(layer)], [dy], dx, post=dx_post)])
+    if gelu_z is not None:
+        bw.conv([ops.conv_problem(pk.d[id(layer)], [dy], dx, pre=dx_post, gelu_z=gelu_z)])
+    else:
+        bw.conv([ops.conv_problem(pk.d[id(layer)], [dy], dx, post=dx_post)])
     return dx
 
 
@@ -292,15 +296,16 @@ def _gelu_bwd(bw, pre: View, dy: View) -> View:
     return o
 
 
-def _ru_bwd(bw, pk, r: dict, d_o: View, grads, need_dx: bool = True) -> Optional[View]:
+def _ru_bwd(bw, pk, r: dict, d_o: View, grads, need_dx: bool = True, d_is_dz: bool = False,
+            in_gelu_z: Optional[View] = None) -> Optional[View]:
+    """``d_is_dz``: ``d_o`` is already dL/d(pre-activation of the unit's last GELU) (its producer applied gelu');
+    ``in_gelu_z``: the unit's input is GELU(z) (the unit in front of it) — return dL/dz instead of dL/dx."""
     ru = r["mod"]
     c1, c2, c3 = ru.conv[0], ru.conv[2], ru.conv[4]
-    dop = _gelu_bwd(bw, r["op"], d_o)
-    d_h2 = _conv_bwd(bw, pk, c3, r["h2"], dop, grads)
-    dh2p = _gelu_bwd(bw, r["h2p"], d_h2)
-    d_h1 = _conv_bwd(bw, pk, c2, r["h1"], dh2p, grads)
-    dh1p = _gelu_bwd(bw, r["h1p"], d_h1)
-    return _conv_bwd(bw, pk, c1, r["x"], dh1p, grads, need_dx, dx_post=dop)          # + the residual path
+    dop = d_o if d_is_dz else _gelu_bwd(bw, r["op"], d_o)
+    dh2p = _conv_bwd(bw, pk, c3, r["h2"], dop, grads, gelu_z=r["h2p"])
+    dh1p = _conv_bwd(bw, pk, c2, r["h1"], dh2p, grads, gelu_z=r["h1p"])
+    return _conv_bwd(bw, pk, c1, r["x"], dh1p, grads, need_dx, dx_post=dop, gelu_z=in_gelu_z)     # + the residual path
 
 
 def _attention_block_bwd(bw, pk, r: dict, dout: View, grads, need_dx: bool) -> Optional[View]:
@@ -308,9 +313,10 @@ def _attention_block_bwd(bw, pk, r: dict, dout: View, grads, need_dx: bool) -> O
     x = r["x"]
     da, db4 = bw.buf(x.B, x.H, x.W, x.C), bw.buf(x.B, x.H, x.W, x.C)
     bw.call(lambda: ops.ew(L.EW_GATE_BWD, [r["a"], r["b4p"], dout], [da, db4]), "gate bwd")
-    d = _conv_bwd(bw, pk, blk.conv_b[4], r["b3"], db4, grads)
-    for rr in reversed(r["b_tape"]):
-        d = _ru_bwd(bw, pk, rr, d, grads)
+    bt, at = r["b_tape"], r["a_tape"]
+    d = _conv_bwd(bw, pk, blk.conv_b[4], r["b3"], db4, grads, gelu_z=bt[-1]["op"])
+    for i in range(len(bt) - 1, -1, -1):
+        d = _ru_bwd(bw, pk, bt[i], d, grads, d_is_dz=True, in_gelu_z=bt[i - 1]["op"] if i > 0 else None)
     wa = blk.conv_b[0]
     d_att = _conv_bwd(bw, pk, wa.attn.proj, r["att"], d, grads)
     dqkv = bw.buf(x.B, x.H, x.W, 3 * x.C)
@@ -322,8 +328,8 @@ def _attention_block_bwd(bw, pk, r: dict, dout: View, grads, need_dx: bool) -> O
             "win_attention bwd")
     dx_b = _conv_bwd(bw, pk, wa.attn.qkv, x, dqkv, grads, need_dx, dx_post=d)          # + the shortcut of the Swin block
     d = da
-    for i, rr in enumerate(reversed(r["a_tape"])):
-        d = _ru_bwd(bw, pk, rr, d, grads, need_dx or i < len(r["a_tape"]) - 1)
+    for i in range(len(at) - 1, -1, -1):
+        d = _ru_bwd(bw, pk, at[i], d, grads, need_dx or i > 0, d_is_dz=i < len(at) - 1, in_gelu_z=at[i - 1]["op"] if i > 0 else None)
     if not need_dx:
         return None
     t, dx = bw.buf(x.B, x.H, x.W, x.C), bw.buf(x.B, x.H, x.W, x.C)
@@ -423,18 +429,24 @@ def lower_lrp_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs
     for d in range(depth):
         zs = []
         probs = []
+        nxt: List[List[View]] = []
         for k in range(K):
             m, act = lay[k][d]
             assert isinstance(m, Ly.Conv2d) and m.stride == 1 and act == (L.ACT_NONE if d == depth - 1 else L.ACT_GELU)
             v0 = cur[k][0]
             z = plan.buf(v0.B, v0.H, v0.W, m.out_channels)
-            probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], z))
+            if d < depth - 1:           # GELU in the epilogue, pre-activation kept as the second output
+                a = plan.buf(v0.B, v0.H, v0.W, m.out_channels)
+                probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], a, L.ACT_GELU, preact=z))
+                nxt.append([a])
+            else:
+                probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], z))
             tapes[k]["x"].append(list(cur[k]))
             tapes[k]["z"].append(z)
             zs.append(z)
         plan.conv(probs)
         if d < depth - 1:
-            cur = [[_gelu(plan, z)] for z in zs]
+            cur = nxt
         else:
             for z, rq, yb, o in zip(zs, rqs, bases, outs):
                 plan.call(lambda z=z, rq=rq, yb=yb, o=o: ops.ew(L.EW_HTANH_FWD, [z, rq, yb], [o]), "lrp tail")
@@ -462,5 +474,5 @@ def lower_lrp_stacks_backward(bw: E.Plan, tapes: Sequence[dict], d_outs: Sequenc
         if d == 0:
             break
         das = [bw.buf(t["z"][d - 1].B, t["z"][d - 1].H, t["z"][d - 1].W, t["z"][d - 1].C) for t in tapes]
-        bw.conv([ops.conv_problem(packs[k].d[id(lay[k][d][0])], [dz[k]], das[k]) for k in range(K)])
-        dz = [_gelu_bwd(bw, tapes[k]["z"][d - 1], das[k]) for k in range(K)]
+        bw.conv([ops.conv_problem(packs[k].d[id(lay[k][d][0])], [dz[k]], das[k], gelu_z=tapes[k]["z"][d - 1]) for k in range(K)])
+        dz = das                          # the launch applied gelu'(z) of the GELU in front of the layer

@@ -345,8 +345,14 @@ def _aux(v: Optional[View]) -> L.VamAux:
 
 def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT_NONE, *,
                  pre: Optional[View] = None, mul: Optional[View] = None, post: Optional[View] = None,
-                 post2: Optional[View] = None, flags: int = 0, out_nchw: Optional[torch.Tensor] = None) -> L.VamConv:
-    """Describe one problem.  ``inputs`` are concatenated along channels (virtually)."""
+                 post2: Optional[View] = None, flags: int = 0, out_nchw: Optional[torch.Tensor] = None,
+                 preact: Optional[View] = None, gelu_z: Optional[View] = None) -> L.VamConv:
+    """Describe one problem.  ``inputs`` are concatenated along channels (virtually).  Training plans: ``preact`` = a second
+    output holding the value the activation is applied to (the taped input of a GELU); ``gelu_z`` = the pre-activation of
+    the GELU in FRONT of this (data-gradient) layer — the result is multiplied by gelu'(z): (conv + bias + pre) * gelu'(z)."""
+    if gelu_z is not None:
+        assert mul is None and act == L.ACT_NONE and type(gelu_z) is View
+        mul, flags = gelu_z, flags | L.CONV_MUL_GELU_GRAD
     c = L.VamConv()
     assert 1 <= len(inputs) <= L.VAM_MAX_SEG
     in3 = isinstance(inputs[0], View3)
@@ -409,6 +415,10 @@ def conv_problem(pk: Packed, inputs: Sequence[View], out: View, act: int = L.ACT
     else:
         assert (Ho - 1) * pk.osy + pk.ooy < c.Hf and (Wo - 1) * pk.osx + pk.oox < c.Wf
     c.pre, c.mul, c.post, c.post2 = _aux(pre), _aux(mul), _aux(post), _aux(post2)
+    if preact is not None:
+        assert type(preact) is View and out_nchw is None and preact.B == B and (preact.H, preact.W) == (c.Hf, c.Wf) and \
+            preact.C == (pk.ps2_cq if pk.ps2_cq else pk.n), "preact is an fp32 NHWC tensor of the output's shape"
+        c.preact = _aux(preact)
     return c
 
 

@@ -93,25 +93,29 @@ def all_reduce_gradients(params) -> int:
         return 0
     dev, dt = params[0].device, params[0].dtype
     n_el = sum(p.numel() for p in params)
+    # (round 4, first run on a device: the per-parameter copy_ / scalar stores of the first version cost 12.9 ms for the 420
+    # REM tensors — 840 tiny launches; now one multi-tensor copy in, one out, and the presence words travel as one vector)
     flat = torch.zeros(n_el + len(params), dtype=dt, device=dev)
-    off = 0
-    for i, p in enumerate(params):
-        if p.grad is not None:
-            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-            flat[n_el + i] = 1.0
+    views, off = [], 0
+    for p in params:
+        views.append(flat[off:off + p.numel()].view(p.shape))
         off += p.numel()
+    have = [i for i, p in enumerate(params) if p.grad is not None]
+    if have:
+        torch._foreach_copy_([views[i] for i in have], [params[i].grad for i in have])
+        flat[n_el:].copy_(torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], dtype=dt), non_blocking=False)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     present = flat[n_el:].tolist()
     flat[:n_el] /= dist.get_world_size()
-    off = 0
+    dst, src = [], []
     for i, p in enumerate(params):
         if present[i] > 0:
-            g = flat[off:off + p.numel()].view_as(p)
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-        off += p.numel()
+                p.grad = torch.empty_like(p)
+            dst.append(p.grad)
+            src.append(views[i])
+    if dst:
+        torch._foreach_copy_(dst, src)
     return flat.numel() * flat.element_size()
 
 

@@ -67,7 +67,11 @@ enum vam_conv_flags {
   VAM_CONV_W_BF16 = 32,     /* wpack comes from vam_pack_conv_weights_bf16: bf16 x bf16 products, one MFMA per block    */
   VAM_CONV_IN_BF16 = 64,    /* every input segment is a bf16 NHWC tensor (seg.ld counts bf16 elements, multiple of 8)   */
   VAM_CONV_OUT_BF16 = 128,  /* store the result as bf16 NHWC (ldo counts bf16 elements)                                 */
-  VAM_CONV_AUX_BF16 = 256   /* pre / mul / post / post2 are bf16 NHWC tensors (their ld counts bf16 elements)           */
+  VAM_CONV_AUX_BF16 = 256,  /* pre / mul / post / post2 are bf16 NHWC tensors (their ld counts bf16 elements)           */
+  /* training (taped forward / backward plans): activations fused into the producing launch */
+  VAM_CONV_MUL_GELU_GRAD = 512 /* the mul operand holds the PRE-ACTIVATION z of a GELU and the result is multiplied by
+                               gelu'(z) instead: out = ... + gelu'(mul) * act(...).  A data-gradient launch then delivers
+                               dL/dz of the GELU in front of the layer directly (autograd of nn.GELU, pic.py:86)     */
 };
 
 #define VAM_MAX_SEG 4
@@ -86,6 +90,7 @@ typedef struct vam_aux {
 
 /*
  * One convolution problem:  out = post2 + post + mul * act(conv(cat(seg...)) + bias + pre)
+ * (and, when preact is set, preact = conv(cat(seg...)) + bias + pre: the taped training forward keeps a GELU's input)
  * Replaces nn.Conv2d / nn.ConvTranspose2d (one sub-pixel phase per problem) /
  * nn.Linear and the element-wise ops the reference applies around them
  * (layers/layers.py:5-86, layers/gdn.py:62-75, layers/rem.py:52-66,130-141,
@@ -115,6 +120,8 @@ typedef struct vam_conv {
                                that wrote it); the launch scales by the largest.  Ignored in the other modes.            */
   int32_t* out_amax;        /* any mode, optional: the epilogue folds max |stored value| into this device cell (integer
                                atomicMax on the float's bits; zero the cell before the first producer of a step)     */
+  vam_aux preact;           /* optional SECOND output (ptr is written): the value the activation is applied to, fp32 NHWC,
+                               indexed like the output (pixel*ld + channel)                                           */
 } vam_conv;
 
 /* sizeof(vam_conv) as compiled into the library (binding layout guard). */
