@@ -1,6 +1,7 @@
 // libvampic runtime pieces: error string, device query, HIP-graph capture helpers and
 // the HIP-event launch profiler used by bench.py's roofline leg.
 #include "common.h"
+#include <unordered_map>
 #include <cstring>
 #include <mutex>
 
@@ -107,6 +108,9 @@ int vam_device_info(char* name128, int* cu_count) {
   return VAM_OK;
 }
 
+static std::mutex g_tmpl_mu;
+static std::unordered_map<void*, hipGraph_t> g_tmpl;     // VAMPIC_GRAPH_KEEP_TEMPLATE=1: executable graph -> its template
+
 int vam_graph_begin(void* stream) {
   VAM_REQUIRE(!g_prof.on, "vam_graph_begin: disable the event profiler before capturing");
   VAM_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
@@ -118,10 +122,18 @@ int vam_graph_end(void* stream, void** exec_out) {
   VAM_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
   hipGraphExec_t ex = nullptr;
   hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
+  // The template graph is not needed once the executable graph exists (CUDA / HIP semantics).  VAMPIC_GRAPH_KEEP_TEMPLATE=1
+  // keeps it until vam_graph_destroy — one of the ingredients the graph-destroy probes toggle.
+  static int keep = -1;
+  if (keep < 0) { const char* k = getenv("VAMPIC_GRAPH_KEEP_TEMPLATE"); keep = (k && k[0] == '1') ? 1 : 0; }
+  if (e != hipSuccess || !keep) (void)hipGraphDestroy(g);
   if (e != hipSuccess) {
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return VAM_EHIP;
+  }
+  if (keep) {
+    std::lock_guard<std::mutex> lk(g_tmpl_mu);
+    g_tmpl[(void*)ex] = g;
   }
   *exec_out = (void*)ex;
   return VAM_OK;
@@ -137,7 +149,16 @@ int vam_graph_destroy(void* exec) {
   // capturing (ops.Graph parks dropped handles and destroys them from the next plan entry point, after synchronising the
   // stream they were last launched on).  Nothing is synchronised here: a device-wide wait from a destructor is illegal
   // inside another plan's stream capture and hid the ordering the caller has to provide anyway.
-  if (exec) VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+  if (exec) {
+    VAM_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+    hipGraph_t g = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_tmpl_mu);
+      auto it = g_tmpl.find(exec);
+      if (it != g_tmpl.end()) { g = it->second; g_tmpl.erase(it); }
+    }
+    if (g) VAM_CHECK_HIP(hipGraphDestroy(g));
+  }
   return VAM_OK;
 }
 

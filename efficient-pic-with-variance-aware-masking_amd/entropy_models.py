@@ -48,6 +48,75 @@ class _EbAuxLoss(torch.autograd.Function):
         return g * dq.view(ctx.shape), None
 
 
+EB_PARAM_NAMES = ("_matrix0", "_bias0", "_factor0", "_matrix1", "_bias1", "_factor1", "_matrix2", "_bias2", "_factor2",
+                  "_matrix3", "_bias3", "_factor3", "_matrix4", "_bias4", "quantiles")
+
+
+class _EbTrainFn(torch.autograd.Function):
+    """Training-mode entropy bottleneck as a module-level call (entropy_models.py:449-492 with ``training=True``):
+    outputs = x + U(-1/2, 1/2), likelihood of the noisy value with compressai's LowerBound(1e-9).  Forward
+    vam_eb_forward_noise, backward vam_eb_train_bwd (dx and the 15 tensors of the density network)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, *params):
+        L.require_gpu()
+        z, nz = ops.from_nchw(x.detach()), ops.from_nchw(noise)
+        pp = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
+        lik = ops.new_view(z.B, z.H, z.W, z.C, x.device)
+        zhat = ops.new_view(z.B, z.H, z.W, z.C, x.device)
+        ops.eb_forward(z, pp, zhat, lik, None, noise=nz)
+        ctx.z, ctx.nz, ctx.pp = z, nz, pp
+        ctx.shapes = [p.shape for p in params]
+        return x.detach() + noise, lik.torch_nchw().contiguous()
+
+    @staticmethod
+    def backward(ctx, g_out, g_lik):
+        z = ctx.z
+        gl = ops.from_nchw(g_lik.contiguous())
+        dz = ops.new_view(z.B, z.H, z.W, z.C, z.buf.device)
+        dpp = torch.zeros_like(ctx.pp)
+        ops.eb_train_bwd(z, ctx.nz, ctx.pp, gl, dz, dpp)
+        dx = dz.torch_nchw()
+        if g_out is not None:
+            dx = dx + g_out
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            grads.append(dpp[off:off + n].view(shp))
+            off += n
+        return (dx, None) + tuple(grads)
+
+
+class _GaussTrainFn(torch.autograd.Function):
+    """Training-mode Gaussian conditional as a module-level call (entropy_models.py:637-652 with ``training=True``):
+    outputs = inputs + U(-1/2, 1/2) (quantize "noise" ignores the means, :132-138), likelihood of outputs - means under
+    max(scales, 0.11) with LowerBound(1e-9); gradients w.r.t. inputs, scales and means incl. both LowerBound rules
+    (vam_gauss_train forward / backward)."""
+
+    @staticmethod
+    def forward(ctx, inputs, scales, means, noise):
+        L.require_gpu()
+        y, sg, nz = ops.from_nchw(inputs.detach()), ops.from_nchw(scales.detach()), ops.from_nchw(noise)
+        mu = ops.from_nchw(means.detach()) if means is not None else ops.new_view(y.B, y.H, y.W, y.C, inputs.device, zero=True)
+        lik = ops.new_view(y.B, y.H, y.W, y.C, inputs.device)
+        ops.gauss_train(y, mu, sg, nz, lik=lik)
+        ctx.views = (y, mu, sg, nz)
+        ctx.has_means = means is not None
+        return inputs.detach() + noise, lik.torch_nchw().contiguous()
+
+    @staticmethod
+    def backward(ctx, g_out, g_lik):
+        y, mu, sg, nz = ctx.views
+        gl = ops.from_nchw(g_lik.contiguous())
+        dmu = ops.new_view(y.B, y.H, y.W, y.C, y.buf.device)
+        dsg = ops.new_view(y.B, y.H, y.W, y.C, y.buf.device)
+        ops.gauss_train(y, mu, sg, nz, grad_lik=gl, dmu=dmu, dsigma=dsg)
+        d_in = -dmu.torch_nchw()                      # the likelihood sees inputs + noise - means
+        if g_out is not None:
+            d_in = d_in + g_out
+        return d_in, dsg.torch_nchw(), (dmu.torch_nchw() if ctx.has_means else None), None
+
+
 class EntropyModel(nn.Module):
     """entropy_models.py:71-294 (buffers and the quantize/dequantize helpers)."""
 
@@ -203,8 +272,9 @@ class EntropyBottleneck(EntropyModel):
         """Eval forward (entropy_models.py:449-492): returns (round(x-med)+med, likelihood)."""
         if training is None:
             training = self.training
-        if training:
-            raise NotImplementedError("training-mode (additive-noise) entropy bottleneck needs the backward kernels; not built yet")
+        if training:                        # additive-noise proxy, differentiable (reference :449-492; used by the harness)
+            noise = torch.empty_like(x).uniform_(-0.5, 0.5)       # entropy_models.py:132-137
+            return _EbTrainFn.apply(x, noise, *[getattr(self, n) for n in EB_PARAM_NAMES])
         _no_autograd(x)
         z = ops.from_nchw(x)
         zhat = ops.new_view(z.B, z.H, z.W, z.C, x.device)
@@ -330,8 +400,9 @@ class GaussianConditional(EntropyModel):
         """Eval forward (entropy_models.py:637-652): (round(x-mu)+mu, likelihood)."""
         if training is None:
             training = self.training
-        if training:
-            raise NotImplementedError("training-mode (additive-noise) likelihood needs the backward kernels; not built yet")
+        if training:                        # additive-noise proxy, differentiable (reference :637-652)
+            noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)  # entropy_models.py:132-137
+            return _GaussTrainFn.apply(inputs, scales, means, noise)
         _no_autograd(inputs, scales, means)
         y = ops.from_nchw(inputs)
         sg = ops.from_nchw(scales)

@@ -60,6 +60,46 @@ def fill(module, seed):
     return sd
 
 
+TRAINED_LIKE_Q = (0, 0.5, 2.5, 10)
+
+
+def section_trained_like(get_model, args):
+    """11. (round 4) The north star's literal tolerances at a realistic rate: the reference's plain ``pic`` model filled with
+    the ``trained-like`` profile of the synthetic generator (vampic.synth: the latent's magnitude and the predicted scales
+    turned down — y - mu is O(1), sigma 0.3 ... 1.3, 0.9 ... 2.5 bpp instead of the default profile's 20 ... 31), two
+    64x64 images and the 256x256 demo image at four qualities.  Stored: mask bit-packs, thresholds, PSNR / bpp scalars
+    (float64 sums over the reference's likelihoods), y_hat and strided x_hat samples."""
+    pargs = argparse.Namespace(**{**vars(args), "model": "pic"})
+    pic = quiet(get_model, pargs, "cpu").eval()
+    torch.nn.Module.load_state_dict(pic, synth.synth_state_dict(pic.state_dict(), 0, profile="trained-like"))
+    rec, scal = {}, {}
+    cases = (("a", synth.synth_image(1, 64, 64, seed=0)), ("b", synth.synth_image(1, 64, 64, seed=1)),
+             ("demo", synth.synth_image(1, 256, 256, seed=0)))
+    with torch.no_grad():
+        for name, x in cases:
+            npix = x.shape[2] * x.shape[3]
+            for q in TRAINED_LIKE_Q:
+                o = pic.forward_single_quality(x, quality=q, training=False)
+                tag = f"{name}_q{q}"
+                small = name != "demo"
+                rec[tag + "_y_hat"] = (o["y_hat"] if small else o["y_hat"][:, ::4, ::2, ::2]).numpy()
+                rec[tag + "_x_hat"] = (o["x_hat"][:, :, ::2, ::2] if small else o["x_hat"][:, :, ::8, ::8]).numpy()
+                if q > 0:
+                    m = torch.cat([pic.masking(s_, pr=q, mask_pol="point-based-std") for s_ in o["std"].chunk(10, 1)], 1)
+                    rec[tag + "_mask"] = np.packbits(m.numpy().astype(np.uint8).reshape(-1))
+                if 0 < q < 10:
+                    rec[tag + "_thr"] = np.array([torch.quantile(s_.ravel(), 1.0 - q * 0.1).item()
+                                                  for s_ in o["std"][0].chunk(10, 0)], dtype=np.float32)
+                mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
+                by = torch.log(o["likelihoods"]["y"].double()).sum().item() / (-np.log(2) * npix)
+                bz = torch.log(o["likelihoods"]["z"].double()).sum().item() / (-np.log(2) * npix)
+                scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": by + bz, "bpp_y": by, "bpp_z": bz,
+                             "abs_y_hat_max": float(o["y_hat"].abs().max())}
+    np.savez_compressed(os.path.join(GOLD, "trained_like.npz"), **rec)
+    with open(os.path.join(GOLD, "trained_like.json"), "w") as f:
+        json.dump(scal, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -72,6 +112,8 @@ def main():
                               mask_policy="point-based-std", support_progressive_slices=5, delta_encode=True,
                               total_mu_rep=True, all_scalable=True, check_levels=[0.75], mu_std=True,
                               dimension="middle")
+    if os.environ.get("VAMPIC_GOLDEN_ONLY") == "trained_like":      # regenerate this one section (minutes instead of the whole run)
+        return section_trained_like(get_model, args)
     net = quiet(get_model, args, "cpu").eval()
 
     # 1. state_dict manifest
@@ -426,6 +468,8 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "config_variants.npz"), **rec)
     with open(os.path.join(GOLD, "config_variants.json"), "w") as f:
         json.dump(scal, f, indent=1)
+
+    section_trained_like(get_model, args)              # 11. trained-like weight profile (round 4)
 
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):

@@ -188,6 +188,34 @@ def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single):
         return O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single, force=force), force
 
 
+def _decision_audit(net, sd, free, force, tol=1e-3):
+    """Hard decisions of the GPU's training forward (``force``: the symbols it took) against the oracle's unforced pass
+    ``free``, stage by stage in dependency order.  Returns {"first": stage name or None, "explained": boundary events of
+    the first differing stage, "violations": its non-boundary differences, "downstream": differences of later stages}."""
+    med = sd["entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    y, C = free["y"].detach(), 32
+    stages = [("z", force["z_sym"], free["z"].detach() - med)]
+    for i in range(10):
+        stages.append((f"base slice {i}", force["base_sym"][:, i * C:(i + 1) * C], y[:, i * C:(i + 1) * C] - free["mu_base"].detach()[:, i * C:(i + 1) * C]))
+    if "prog_sym" in force:
+        for j in range(10):
+            r = y[:, 320 + j * C:320 + (j + 1) * C] - y[:, j * C:(j + 1) * C]
+            stages.append((f"progressive slice {j}", force["prog_sym"][:, j * C:(j + 1) * C], r - free["mu"].detach()[:, j * C:(j + 1) * C]))
+    rep = {"first": None, "explained": 0, "violations": 0, "downstream": 0}
+    for name, sym, t in stages:
+        differ = sym != torch.round(t)
+        n = int(differ.sum())
+        if n == 0:
+            continue
+        if rep["first"] is None:
+            dist = 0.5 - (t - torch.round(t)).abs()
+            bad = int((differ & (dist >= tol)).sum())
+            rep.update(first=name, explained=n - bad, violations=bad)
+        else:
+            rep["downstream"] += n
+    return rep
+
+
 def _compare_grads(net, ref_grads):
     params = dict(net.named_parameters())
     want = sorted(k for k, g in ref_grads.items() if g is not None)
@@ -245,10 +273,21 @@ def test_first_train_step_matches_reference(use_graph):
     crit = ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device="cuda")(out, x.cuda())
     crit["loss"].backward()
     force = _check_step(net, sd, out, crit, x, ny, nz, [0, 10], [0.0055, 0.04], False, f"first_train graph={use_graph}")
-    # how far the decisions themselves are from the reference's run: differing roundings must be few
+    # how far the decisions themselves are from the reference's run: the oracle's UNFORCED step is the
+    # reference's run (CPU suite, tests/golden/first_train_step.npz); walking the hard decisions in dependency order
+    # (z, base slices 0..9, progressive slices 0..9), the FIRST stage that differs must differ only in rounding-boundary
+    # events of the oracle's own numbers (residual within 1e-3 of x.5); everything after it is conditioned on them and is
+    # only counted.  A wrong kernel differs in non-boundary elements of an untainted stage.
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        free = O.training_forward(sd, x, [0, 10], ny, nz)
+    rep = _decision_audit(net, sd, free, force)
     gold = np.load(os.path.join(GOLD, "first_train_step.npz"))
     flips = int((( _plan_of(net).y_base.torch_nchw().cpu() - torch.from_numpy(gold["y_hat_base"])).abs() > 0.4).sum())
-    print("base latents whose rounding differs from the reference's run (incl. conditioned ones):", flips, "of", gold["y_hat_base"].size)
+    print(f"first_train graph={use_graph}: decision audit {rep}; base latents differing from the reference's run "
+          f"(incl. conditioned ones): {flips} of {gold['y_hat_base'].size}")
+    assert rep["violations"] == 0, rep
+    assert rep["explained"] <= 8, rep                    # measured (r04): see DESIGN.md section 9c
     assert flips <= 0.05 * gold["y_hat_base"].size
 
 

@@ -94,6 +94,54 @@ def test_gauss_train_matches_oracle_autograd(masked):
     assert float((sg.grad == 0).float().mean()) > 0.01       # the bounds did clip some gradients
 
 
+def test_module_level_training_forwards_are_differentiable():
+    """``gaussian_conditional(y, sigma, mu, training=True)`` and ``entropy_bottleneck(z, training=True)`` called on the
+    modules themselves (as the reference's harness may: entropy_models.py:449-492,637-652): outputs = input + U(-1/2, 1/2),
+    likelihoods and their gradients w.r.t. every input / parameter against autograd over the oracle with the same noise."""
+    from vampic import entropy_models as EM
+    shp = (2, 64, 8, 8)
+    y = synth.normal(shp, 1, 4.0).requires_grad_(True)
+    mu = synth.normal(shp, 3, 2.0).requires_grad_(True)
+    sg = (synth.synth_sigma(2, 64 * 64, seed=4).reshape(shp) * 0.5).requires_grad_(True)
+    nz = synth.uniform(shp, 5) - 0.5
+    g = synth.normal(shp, 7)
+    O.gaussian_likelihood_noise(y, sg, mu, nz).backward(g)
+    yg, mg, sgg = (t.detach().clone().cuda().requires_grad_(True) for t in (y, mu, sg))
+    out, lik = EM._GaussTrainFn.apply(yg, sgg, mg, nz.cuda())
+    lik.backward(g.cuda())
+    assert torch.equal(out.cpu(), y.detach() + nz)
+    for got, ref in ((yg.grad, y.grad), (mg.grad, mu.grad), (sgg.grad, sg.grad)):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
+    gc = EM.GaussianConditional(None).cuda().train()
+    out, lik = gc(yg, sgg, mg)                                   # draws its own noise (torch's generator, as the reference)
+    d = (out - yg).detach()
+    assert float(d.abs().max()) <= 0.5 and float(d.std()) > 0.2 and bool((lik > 0).all()) and lik.requires_grad
+    # entropy bottleneck
+    eb = EM.EntropyBottleneck(192)
+    sd = synth.synth_state_dict(eb.state_dict(), 40)
+    eb.load_state_dict(sd)
+    eb = eb.cuda().train()
+    z = synth.normal((2, 192, 4, 6), 41, 5.0)
+    nzz = synth.uniform((2, 192, 4, 6), 42) - 0.5
+    gz = synth.normal((2, 192, 4, 6), 43)
+    leaves = {"entropy_bottleneck." + k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and k != "target"}
+    zr = z.clone().requires_grad_(True)
+    O.eb_likelihood_noise_bounded(leaves, zr, nzz).backward(gz)
+    zg = z.clone().cuda().requires_grad_(True)
+    out, lik = EM._EbTrainFn.apply(zg, nzz.cuda(), *[getattr(eb, n) for n in EM.EB_PARAM_NAMES])
+    lik.backward(gz.cuda())
+    assert float((zg.grad.cpu() - zr.grad).abs().max()) <= 5e-5 * float(zr.grad.abs().max()) + 1e-7
+    for n in EM.EB_PARAM_NAMES:
+        want = leaves["entropy_bottleneck." + n].grad
+        got = getattr(eb, n).grad
+        if n == "quantiles":
+            assert float(got.abs().max()) == 0.0 and (want is None or float(want.abs().max()) == 0.0)
+        else:
+            assert float((got.cpu() - want).abs().max()) <= 5e-5 * float(want.abs().max()) + 1e-7, n
+    out, lik = eb(zg)                                            # module call in training mode
+    assert float((out - zg).abs().max()) <= 0.5 and lik.requires_grad and tuple(lik.shape) == tuple(zg.shape)
+
+
 def test_rem_blocks_backward_teacher_forced():
     """Taped REM forward + backward lowering (engine.lower_rem_blocks_train / lower_rem_backward) on IDENTICAL
     inputs against autograd over the oracle's rem_block: outputs 1e-5, every parameter gradient 2e-5 of its max."""

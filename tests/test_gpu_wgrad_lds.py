@@ -73,9 +73,10 @@ def test_mixed_group_routes_each_problem_to_its_kernel():
         F.conv2d(x, w, None, padding=k // 2).backward(dy)
         dw = torch.full((n, c, k, k), float("nan"), device="cuda")
         db = torch.full((n,), float("nan"), device="cuda")
-        probs += ops.wgrad_problems([ops.from_nchw(x.cuda())], ops.from_nchw(dy.cuda()), dw, db)
-        out.append((dw, w.grad, db, dy.sum((0, 2, 3))))
+        xv, dyv = ops.from_nchw(x.cuda()), ops.from_nchw(dy.cuda())      # (the problem structs hold raw pointers: keep the views)
+        probs += ops.wgrad_problems([xv], dyv, dw, db)
+        out.append((dw, w.grad, db, dy.sum((0, 2, 3)), xv, dyv))
     ops.wgrad_group(probs)
     torch.cuda.synchronize()
-    for dw, ref, db, refb in out:
+    for dw, ref, db, refb, _, _ in out:
         assert _rel(dw, ref) <= 2e-5 and _rel(db, refb) <= 2e-5

@@ -348,3 +348,35 @@ def test_oracle_first_train_step_matches_reference(fixture, qualities, lmbda, si
         num += float(((s_ - ref).astype(np.float64) ** 2).sum())
         den += float((ref.astype(np.float64) ** 2).sum())
     assert (num / den) ** 0.5 <= 1e-5
+
+
+def test_oracle_reproduces_reference_trained_like_profile():
+    """Round 4: the ``trained-like`` profile of the synthetic generator (rate 0.9 ... 2.5 bpp, |y_hat| <= 2 — a trained
+    codec's operating range, where the north star's absolute tolerances apply literally): the oracle against the vectors
+    the REFERENCE produced (oracle/gen_golden.py section 11) — masks and thresholds exactly, PSNR 1e-4 dB, bpp 1e-6."""
+    import argparse
+    import vampic
+    from conftest import README_ARGS
+    gold = np.load(os.path.join(GOLD, "trained_like.npz"))
+    scal = json.load(open(os.path.join(GOLD, "trained_like.json")))
+    net = vampic.get_model(argparse.Namespace(model="pic", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0, profile="trained-like")
+    assert all(0.3 <= v["bpp"] <= 3.0 and v["abs_y_hat_max"] < 4 for v in scal.values())
+    for name, x, qs in (("a", synth.synth_image(1, 64, 64, seed=0), (0, 0.5, 2.5, 10)),
+                        ("b", synth.synth_image(1, 64, 64, seed=1), (0, 0.5, 2.5, 10)),
+                        ("demo", synth.synth_image(1, 256, 256, seed=0), (2.5,))):
+        npix = x.shape[2] * x.shape[3]
+        for q in qs:
+            tag = f"{name}_q{q}"
+            o = O.forward_single_quality(sd, x, q)
+            small = name != "demo"
+            _close(o["y_hat"] if small else o["y_hat"][:, ::4, ::2, ::2], gold[tag + "_y_hat"], 2e-5)
+            _close(o["x_hat"][:, :, ::2, ::2] if small else o["x_hat"][:, :, ::8, ::8], gold[tag + "_x_hat"], 2e-5)
+            if q > 0:
+                assert np.array_equal(np.packbits(o["mask"].numpy().astype(np.uint8).reshape(-1)), gold[tag + "_mask"]), tag
+            if 0 < q < 10:
+                thr = np.array([O.quantile_threshold_np(s_.numpy().ravel(), q * 0.1) for s_ in o["std"][0].chunk(10, 0)],
+                               dtype=np.float32)
+                assert np.array_equal(thr, gold[tag + "_thr"]), tag
+            assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4, tag
+            assert abs(O.bpp(o["likelihoods"], npix) - scal[tag]["bpp"]) <= 1e-6, tag
