@@ -34,16 +34,18 @@ struct Wgrad2Args {
   vam_wgrad p[VAM_MAX_WGRAD_GROUP];
 };
 
-constexpr int W2_NB = 128, W2_CB = 64, W2_KP = 64, W2_NT = 512;
-constexpr int W2_SY_BYTES = (W2_NB / 32) * 3 * W2_KP * 64;            // 49,152
+// A workgroup is WN x WC waves, each owning one 32 x 32 block of the (32 WN) x (32 WC) weight tile for all kw taps.  The
+// grid of waves is a template parameter: layers whose channel counts are multiples of 96 (96 -> 96, 192 -> 192, 176 padded
+// to 192) waste a quarter of a 128-row tile, 16-channel inputs three quarters of a 64-column one (wgrad2_tile()).
 
 // LDS pixels of the input tile: R image rows of XWL pixel slots each (stride 2: even columns, then odd columns)
 __host__ __device__ constexpr int w2_xw(int segw, int kw, int stride) { return (segw - 1) * stride + kw; }
 __host__ __device__ constexpr int w2_xwl(int segw, int kw, int stride) {
   return stride == 2 ? 2 * ((w2_xw(segw, kw, stride) + 1) / 2) : w2_xw(segw, kw, stride);
 }
-__host__ __device__ constexpr int w2_xp_max(int kw, int stride) {      // over SEGW in {16 (R = 4), 32 (R = 2), 64 (R = 1)}
-  const int a = 4 * w2_xwl(16, kw, stride), b = 2 * w2_xwl(32, kw, stride), c = w2_xwl(64, kw, stride);
+__host__ __device__ constexpr int w2_xp_max(int kw, int stride, int kp) {   // over SEGW in {16, 32, 64} <= KP, R = KP / SEGW rows
+  const int a = (kp / 16) * w2_xwl(16, kw, stride), b = kp >= 32 ? (kp / 32) * w2_xwl(32, kw, stride) : 0,
+            c = kp >= 64 ? w2_xwl(64, kw, stride) : 0;
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
@@ -62,11 +64,17 @@ __device__ __forceinline__ void w2_split4(const u32x4 v, uint2 (&pl)[3]) {
   pl[2] = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
 }
 
-template <int KW, int STRIDE>
-__global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
+template <int KW, int STRIDE, int WN, int WC, int W2_KP>
+__global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int XP_MAX = w2_xp_max(KW, STRIDE);
-  constexpr int NXU = (XP_MAX * 16 + W2_NT - 1) / W2_NT;      // 16-byte units of the input tile per thread
+  constexpr int W2_NB = 32 * WN, W2_CB = 32 * WC, W2_NT = 64 * WN * WC;
+  constexpr int LGKP = W2_KP == 64 ? 6 : 5;                   // chunk = 64 or 32 output pixels
+  constexpr int W2_SY_BYTES = WN * 3 * W2_KP * 64;
+  constexpr int UY = W2_NB / 4, UX = W2_CB / 4;               // 16-byte units per pixel of the dY / input tile
+  constexpr int PY = W2_NT / UY, PX = W2_NT / UX;             // pixels one pass of the workgroup stages (8 WC, 8 WN)
+  constexpr int NYU = (W2_KP + PY - 1) / PY;                  // passes over the 64 dY pixels
+  constexpr int XP_MAX = w2_xp_max(KW, STRIDE, W2_KP);
+  constexpr int NXU = (XP_MAX + PX - 1) / PX;                 // passes over the input tile's pixels
   constexpr int PAD = KW / 2;
   unsigned char* sY = smem;
   unsigned char* sX = smem + W2_SY_BYTES;
@@ -85,14 +93,14 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int H = pr.H, W = pr.W, HW = H * W;
   const int Hx = STRIDE == 2 ? pr.Hx : H, Wx = STRIDE == 2 ? pr.Wx : W;
-  const int SEGW = W < 64 ? W : 64;                             // host: W in {16, 32} or a multiple of 64; H * W % 64 == 0
+  const int SEGW = W < W2_KP ? W : W2_KP;                       // host: W in {16, 32} or a multiple of 64; H * W % 64 == 0
   const int lg = SEGW == 64 ? 6 : (SEGW == 32 ? 5 : 4);
-  const int R = 64 >> lg;
+  const int R = W2_KP >> lg;
   const int XW = (SEGW - 1) * STRIDE + KW;
   const int XWH = (XW + 1) >> 1;
   const int XWL = STRIDE == 2 ? 2 * XWH : XW;
   const int XPL = R * XWL;                                      // LDS pixel slots per (channel block, plane)
-  const int n_chunks = (int)(((long)pr.B * HW) >> 6);
+  const int n_chunks = (int)(((long)pr.B * HW) >> LGKP);
   const int chunks_per = (n_chunks + S - 1) / S;
   const int q_begin = split * chunks_per;
   const int q_end = q_begin + chunks_per < n_chunks ? q_begin + chunks_per : n_chunks;
@@ -107,19 +115,20 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
   const unsigned OOB = 0x80000000u;
 
   // ---- staging roles (fixed per thread over all chunks)
-  // dY: unit u = tid + 512 i -> pixel tid / 32 + 16 i, channels 4 (tid % 32) .. + 3 of the tile
-  const int ycc = (tid & 31) * 4;                               // channel inside the 128-channel tile
+  // dY: unit u = tid + NT i -> pixel tid / UY + PY i, channels 4 (tid % UY) .. + 3 of the tile
+  const int ycc = (tid % UY) * 4;                               // channel inside the tile
+  const int ypx = tid / UY;
   const bool y_ok = n0 + ycc < N;                               // (host: N % 4 == 0)
-  const unsigned y_src = (unsigned)(((tid >> 5) * pr.ld_dy + n0 + ycc) << 2);         // + (p0 + 16 i) * ld_dy * 4
-  const unsigned y_dst = (unsigned)(((ycc >> 5) * 3 * W2_KP + (tid >> 5)) * 64 + (ycc & 31) * 2);   // + plane * 64 * 64 + 16 i * 64
-  // X: unit u = tid + 512 i -> tile pixel tid / 16 + 32 i, channels 4 (tid % 16) .. + 3
-  const int xcc = (tid & 15) * 4;
+  const unsigned y_src = (unsigned)((ypx * pr.ld_dy + n0 + ycc) << 2);                 // + (p0 + PY i) * ld_dy * 4
+  const unsigned y_dst = (unsigned)(((ycc >> 5) * 3 * W2_KP + ypx) * 64 + (ycc & 31) * 2);   // + plane * 64 * 64 + PY i * 64
+  // X: unit u = tid + NT i -> tile pixel tid / UX + PX i, channels 4 (tid % UX) .. + 3
+  const int xcc = (tid % UX) * 4;
   const bool xc_ok = c0 + xcc < C;                              // (host: C % 4 == 0)
   int x_r[NXU], x_j[NXU];
   unsigned x_dst[NXU];
 #pragma unroll
   for (int i = 0; i < NXU; ++i) {
-    const int xp = (tid >> 4) + 32 * i;                         // pixel of the tile in raster order: row r, column j
+    const int xp = tid / UX + PX * i;                           // pixel of the tile in raster order: row r, column j
     const int r = xp / XW, j = xp - r * XW;
     x_r[i] = xp < R * XW ? r : -1;
     x_j[i] = j;
@@ -127,16 +136,17 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
     x_dst[i] = (unsigned)(((xcc >> 5) * 3 * XPL + lp) * 64 + (xcc & 31) * 2);          // + plane * XPL * 64
   }
 
-  u32x4 ry[4], rx[NXU];
+  u32x4 ry[NYU], rx[NXU];
   auto issue = [&](int q) {
-    const int p0 = q << 6;
+    const int p0 = q << LGKP;
     const int b = p0 / HW;
     const int rem = p0 - b * HW;
     const int oy0 = rem / W, ox0 = rem - oy0 * W;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned o = y_src + (unsigned)((p0 + 16 * i) * pr.ld_dy) * 4u;
-      ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, (int)(y_ok ? o : OOB), 0, 0));
+    for (int i = 0; i < NYU; ++i) {
+      const unsigned o = y_src + (unsigned)((p0 + PY * i) * pr.ld_dy) * 4u;
+      const bool ok = y_ok && (W2_KP % PY == 0 || ypx + PY * i < W2_KP);
+      ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, (int)(ok ? o : OOB), 0, 0));
     }
     const int ix0 = ox0 * STRIDE - PAD;
 #pragma unroll
@@ -151,14 +161,16 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   auto stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint2 pl[3];
-      w2_split4(ry[i], pl);
+    for (int i = 0; i < NYU; ++i) {
+      if (W2_KP % PY == 0 || ypx + PY * i < W2_KP) {
+        uint2 pl[3];
+        w2_split4(ry[i], pl);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sY + y_dst + k * (W2_KP * 64) + i * (16 * 64)) = pl[k];
-      if (want_db) {
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sY + y_dst + k * (W2_KP * 64) + i * (PY * 64)) = pl[k];
+        if (want_db) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bs[e] += __uint_as_float(ry[i][e]);
+          for (int e = 0; e < 4; ++e) bs[e] += __uint_as_float(ry[i][e]);
+        }
       }
     }
 #pragma unroll
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
   };
 
   // ---- compute roles: wave = one 32 x 32 block of the tile, all KW taps
-  const int nb = wid & 3, cb = wid >> 2;
+  const int nb = wid % WN, cb = wid / WN;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   // transposed read: lane 4 q + p of 16-lane group g supplies pixel row q, channels 16 (g & 1) + 4 p .. + 3; the group
   // receives pixels 8 (g >> 1) + 4 h + {0..3} of channel 16 (g & 1) + (lane & 15)
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
   };
   auto compute = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < W2_KP / 16; ++ks) {
       const int r = (ks * 16) >> lg, oxs = (ks * 16) & (SEGW - 1);
       bf16x8 fa[3];
 #pragma unroll
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
 
   // LDS slots the loader never writes must read as zero: pixel slots of the de-interleaved rows beyond XW
   if (STRIDE == 2) {
-    for (int i = tid; i < 2 * 3 * XPL * 4; i += W2_NT) reinterpret_cast<uint4*>(sX)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < WC * 3 * XPL * 4; i += W2_NT) reinterpret_cast<uint4*>(sX)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
   if (q_begin < q_end) {
@@ -257,21 +269,23 @@ __global__ __launch_bounds__(W2_NT) void wgrad2_kernel(const Wgrad2Args args) {
     }
   }
   if (want_db) {                                                // block-uniform
-    float* red = reinterpret_cast<float*>(smem);                // [16 pixel groups][128 channels]; the tiles are dead
+    float* red = reinterpret_cast<float*>(smem);                // [PY pixel groups][NB channels]; the tiles are dead
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[(tid >> 5) * W2_NB + ycc + e] = bs[e];
+    for (int e = 0; e < 4; ++e) red[ypx * W2_NB + ycc + e] = bs[e];
     __syncthreads();
     if (tid < W2_NB && n0 + tid < N) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k * W2_NB + tid];
+      for (int k = 0; k < PY; ++k) t += red[k * W2_NB + tid];
       if (part) part[(size_t)N * C * taps + n0 + tid] = t;
       else pr.db[n0 + tid] = t;
     }
   }
 }
 
-static size_t w2_lds_bytes(int kw, int stride) { return (size_t)W2_SY_BYTES + (size_t)2 * 3 * w2_xp_max(kw, stride) * 64; }
+static size_t w2_lds_bytes(int kw, int stride, int wn, int wc, int kp) {
+  return (size_t)wn * 3 * kp * 64 + (size_t)wc * 3 * w2_xp_max(kw, stride, kp) * 64;
+}
 
 // ---------------------------------------------------------------------------------------------------- host side
 // A problem takes this kernel when its geometry is the one the chunking assumes; everything else (1x1 layers, the small
@@ -293,46 +307,117 @@ bool wgrad2_eligible(const vam_wgrad& p) {
   return true;
 }
 
-int wgrad2_splits(const vam_wgrad& p) {
-  // blocks per split: kh * n tiles * c tiles; aim at ~2 blocks per CU over the chip, at least 16 chunks (1024 pixels) per
-  // split — every split writes its partial tile (N C taps floats) and the reduce kernel reads them all back
-  const long per = (long)p.kh * cdiv(p.N, W2_NB) * cdiv(p.C, W2_CB);
-  const long chunks = ((long)p.B * p.H * p.W) >> 6;
-  long s = (512 + per - 1) / per;
-  const long cap = chunks / 16;
-  if (s > cap) s = cap;
-  if (s > 256) s = 256;
-  return s < 2 ? 1 : (int)s;
+// wave grid of a problem: the candidate with the least padded work (ties: the larger tile, less re-staging)
+struct W2Tile { int wn, wc, kp; };
+static const W2Tile w2_tiles[] = {{4, 2, 64}, {3, 2, 64}, {2, 2, 64}, {4, 1, 64}, {3, 3, 64}};
+static int w2_force_kp() {                                      // VAMPIC_WGRAD_KP=32|64: chunk size (measurements)
+  static int kp = -1;
+  if (kp < 0) { const char* e = getenv("VAMPIC_WGRAD_KP"); kp = e ? atoi(e) : 0; }
+  return kp == 32 || kp == 64 ? kp : 0;
+}
+W2Tile wgrad2_tile(const vam_wgrad& p) {
+  static int fn = -1, fc = -1;                                  // VAMPIC_WGRAD_TILE="wn,wc": force one grid (measurements)
+  if (fn < 0) {
+    fn = fc = 0;
+    if (const char* e = getenv("VAMPIC_WGRAD_TILE")) sscanf(e, "%d,%d", &fn, &fc);
+  }
+  // stride-2 layers stage (2 SEGW + kw) input pixels per row: 32-pixel chunks keep two workgroups per CU
+  const int kp = w2_force_kp() ? w2_force_kp() : (p.stride == 2 ? 32 : 64);
+  if (fn > 0)
+    for (const W2Tile& t : w2_tiles)
+      if (t.wn == fn && t.wc == fc) return W2Tile{t.wn, t.wc, kp};
+  W2Tile best = w2_tiles[0];
+  double best_cost = 1e300;
+  for (const W2Tile& t : w2_tiles) {
+    if (t.wn == 3 && t.wc == 3) continue;                       // nine-wave blocks: measured, not chosen automatically
+    const double area = (double)cdiv(p.N, 32 * t.wn) * 32 * t.wn * cdiv(p.C, 32 * t.wc) * 32 * t.wc;
+    const double cost = area * (1.0 + 0.02 * (8 - t.wn * t.wc));     // mild preference for the larger tiles
+    if (cost < best_cost) { best_cost = cost; best = t; }
+  }
+  best.kp = kp;
+  return best;
 }
 
-template <int KW, int STRIDE>
+int wgrad2_splits(const vam_wgrad& p) {
+  // Pixel splits of ONE problem.  A workgroup slot is a CU x (workgroups that fit its LDS); with `per` tiles (kernel rows x
+  // n tiles x c tiles) and S splits the launch runs ceil(per S / slots) rounds of ceil(chunks / S) chunks each.  Pick the S
+  // with the shortest makespan (r04: 30 tiles x 18 splits = 540 workgroups on 256 slots ran a third, nearly empty round;
+  // 17 splits do not), plus what a split costs: its partial tile is written once and read back by the reduce kernel.
+  const W2Tile t = wgrad2_tile(p);
+  const int stride = p.stride == 2 ? 2 : 1;
+  const long per = (long)p.kh * cdiv(p.N, 32 * t.wn) * cdiv(p.C, 32 * t.wc);
+  const long chunks = ((long)p.B * p.H * p.W) / t.kp;
+  const size_t lds = w2_lds_bytes(p.kh, stride, t.wn, t.wc, t.kp);
+  long wg_per_cu = (long)(160 * 1024 / lds);
+  const long by_waves = 16 / (t.wn * t.wc);                     // four waves per SIMD at most for these register counts
+  if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  const long slots = 256 * wg_per_cu;                           // MI355X: 256 CUs
+  const long min_chunks = 1024 / t.kp;                          // at least 1024 pixels per split
+  long cap = chunks / min_chunks;
+  if (cap > 256) cap = 256;
+  long best_s = 1;
+  double best_cost = 1e300;
+  for (long s = 1; s <= (cap < 1 ? 1 : cap); ++s) {
+    const double rounds = (double)((per * s + slots - 1) / slots);
+    const double work = rounds * (double)((chunks + s - 1) / s);
+    const double cost = work + (s > 1 ? 0.25 * s * (64.0 / t.kp) : 0.0);    // one partial tile ~ a quarter of a 64-pixel chunk's time
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_s = s; }
+  }
+  return (int)best_s;
+}
+
+template <int KW, int STRIDE, int WN, int WC, int KP>
 static int w2_launch(const Wgrad2Args& a, int max_blocks, int n_sub, hipStream_t s) {
   static bool attr = false;
-  const size_t lds = w2_lds_bytes(KW, STRIDE);
+  const size_t lds = w2_lds_bytes(KW, STRIDE, WN, WC, KP);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE, WN, WC, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE>), dim3(max_blocks, n_sub), dim3(W2_NT), lds, s, a);
+  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE, WN, WC, KP>), dim3(max_blocks, n_sub), dim3(64 * WN * WC), lds, s, a);
   return check_launch("wgrad2_kernel");
 }
 
-// problems of one (kernel size, stride) class, all eligible
+template <int WN, int WC>
+static int w2_launch_ks(int kw, int st, int kp, const Wgrad2Args& a, int max_blocks, int n, hipStream_t stream) {
+#define W2_KS(KW_, ST_)                                                                      \
+  if (kw == KW_ && st == ST_)                                                                \
+    return kp == 32 ? w2_launch<KW_, ST_, WN, WC, 32>(a, max_blocks, n, stream) : w2_launch<KW_, ST_, WN, WC, 64>(a, max_blocks, n, stream);
+  W2_KS(3, 1) W2_KS(5, 1) W2_KS(3, 2)
+#undef W2_KS
+  return kp == 32 ? w2_launch<5, 2, WN, WC, 32>(a, max_blocks, n, stream) : w2_launch<5, 2, WN, WC, 64>(a, max_blocks, n, stream);
+}
+
+// eligible problems of one (kernel size, stride) class: one launch per wave grid
 int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
-  Wgrad2Args a;
-  int max_blocks = 0;
-  for (int i = 0; i < n; ++i) {
-    a.p[i] = probs[i];
-    const vam_wgrad& p = probs[i];
-    const int S = p.splits > 1 ? p.splits : 1;
-    const int nb = p.kh * cdiv(p.N, W2_NB) * cdiv(p.C, W2_CB) * S;
-    max_blocks = nb > max_blocks ? nb : max_blocks;
-  }
+  bool done[VAM_MAX_WGRAD_GROUP] = {};
   const int kw = probs[0].kh, st = probs[0].stride == 2 ? 2 : 1;
-  if (kw == 3 && st == 1) return w2_launch<3, 1>(a, max_blocks, n, stream);
-  if (kw == 5 && st == 1) return w2_launch<5, 1>(a, max_blocks, n, stream);
-  if (kw == 3 && st == 2) return w2_launch<3, 2>(a, max_blocks, n, stream);
-  return w2_launch<5, 2>(a, max_blocks, n, stream);
+  for (int i0 = 0; i0 < n; ++i0) {
+    if (done[i0]) continue;
+    const W2Tile t = wgrad2_tile(probs[i0]);
+    Wgrad2Args a;
+    int n_sub = 0, max_blocks = 0;
+    for (int i = i0; i < n; ++i) {
+      if (done[i]) continue;
+      const W2Tile ti = wgrad2_tile(probs[i]);
+      if (ti.wn != t.wn || ti.wc != t.wc || ti.kp != t.kp) continue;
+      done[i] = true;
+      const vam_wgrad& p = probs[i];
+      a.p[n_sub++] = p;
+      const int S = p.splits > 1 ? p.splits : 1;
+      const int nb = p.kh * cdiv(p.N, 32 * t.wn) * cdiv(p.C, 32 * t.wc) * S;
+      max_blocks = nb > max_blocks ? nb : max_blocks;
+    }
+    int rc;
+    if (t.wn == 4 && t.wc == 2) rc = w2_launch_ks<4, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    else if (t.wn == 3 && t.wc == 2) rc = w2_launch_ks<3, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    else if (t.wn == 2 && t.wc == 2) rc = w2_launch_ks<2, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    else if (t.wn == 4 && t.wc == 1) rc = w2_launch_ks<4, 1>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    else rc = w2_launch_ks<3, 3>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    if (rc) return rc;
+  }
+  return VAM_OK;
 }
 
 }  // namespace vam

@@ -105,7 +105,10 @@ def all_reduce_gradients(params) -> int:
         torch._foreach_copy_([views[i] for i in have], [params[i].grad for i in have])
         flat[n_el:].copy_(torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], dtype=dt), non_blocking=False)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    present = flat[n_el:].tolist()
+    # which parameters received a gradient on SOME rank: known without asking the device when this rank has them all (the
+    # usual case — the job draws one quality per step, so every rank trains the same REM); reading the presence words back
+    # is a device-to-host synchronisation that stops the host from running ahead of the GPU (measured: +7 ms per step)
+    present = [1.0] * len(params) if len(have) == len(params) else flat[n_el:].tolist()
     flat[:n_el] /= dist.get_world_size()
     dst, src = [], []
     for i, p in enumerate(params):

@@ -15,6 +15,30 @@ def pytest_configure(config):
     vampic.synth.memoize(True)      # the dozen model variants of a session share their synthetic tensors (seconds per model)
 
 
+# Quantities the parity tests MEASURE (difference-free case counts, worst |dbpp|, boundary events of the training step ...):
+# shown at the end of the run even under -q, and written to gpurun_out/parity_measured.json on the GPU box, so that the
+# numbers DESIGN.md quotes are the test run's own.
+MEASURED = []
+
+
+def record_measurement(name: str, **values):
+    MEASURED.append((name, values))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not MEASURED:
+        return
+    terminalreporter.section("measured parity quantities")
+    for name, values in MEASURED:
+        terminalreporter.write_line(f"{name}: " + ", ".join(f"{k} = {v}" for k, v in values.items()))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "parity_measured.json"), "w") as f:
+            json.dump([{"test": n, **{k: (v if isinstance(v, (int, float, str, type(None))) else str(v)) for k, v in vals.items()}}
+                       for n, vals in MEASURED], f, indent=1)
+
+
 README_ARGS = dict(N=192, M=640, multiple_decoder=True, multiple_encoder=True, multiple_hyperprior=True,
                    dim_chunk=32, division_dimension=[320, 640], mask_policy="point-based-std",
                    support_progressive_slices=5, delta_encode=True, total_mu_rep=True, all_scalable=True)

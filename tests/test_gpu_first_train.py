@@ -286,6 +286,10 @@ def test_first_train_step_matches_reference(use_graph):
     flips = int((( _plan_of(net).y_base.torch_nchw().cpu() - torch.from_numpy(gold["y_hat_base"])).abs() > 0.4).sum())
     print(f"first_train graph={use_graph}: decision audit {rep}; base latents differing from the reference's run "
           f"(incl. conditioned ones): {flips} of {gold['y_hat_base'].size}")
+    from conftest import record_measurement
+    record_measurement(f"first_train step vs the reference's run (graph={use_graph})", first_differing_stage=rep["first"],
+                       boundary_events=rep["explained"], violations=rep["violations"], downstream=rep["downstream"],
+                       base_latents_differing=f"{flips}/{gold['y_hat_base'].size}")
     assert rep["violations"] == 0, rep
     assert rep["explained"] <= 8, rep                    # measured (r04): see DESIGN.md section 9c
     assert flips <= 0.05 * gold["y_hat_base"].size

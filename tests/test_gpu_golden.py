@@ -143,6 +143,8 @@ def test_demo_image_256_matches_reference_vectors(gpu_model):
         bpp = -cpu["log2_likelihood_sum"].sum().item() / 65536
         check_bpp_abs(bpp, scal[tag]["bpp"], tag)                    # ABSOLUTE (conftest.bpp_tol: max(1e-6, 4 fp32 ulps of the rate))
     print(f"256x256 demo image: {clean}/{total} quality levels reproduced in every rounding decision")
+    from conftest import record_measurement
+    record_measurement("256x256 demo image, default profile", difference_free=f"{clean}/{total}")
     assert clean >= min_clean_cases(total), f"only {clean}/{total} quality levels reproduced in every rounding decision"
 
 
@@ -203,4 +205,7 @@ def test_trained_like_profile_meets_the_literal_tolerances():
             assert d_psnr <= 1e-4, (tag, d_psnr)
             assert d_bpp <= 1e-6, (tag, d_bpp)            # ABSOLUTE, no relative escape
     print(f"trained-like profile: {clean}/{total} cases difference-free; worst |dbpp| {worst_bpp:.2e}, worst |dPSNR| {worst_psnr:.2e} dB")
+    from conftest import record_measurement
+    record_measurement("trained-like profile (literal tolerances)", difference_free=f"{clean}/{total}", worst_dbpp=f"{worst_bpp:.2e}",
+                       worst_dpsnr_db=f"{worst_psnr:.2e}")
     assert clean >= int(np.ceil(0.9 * total)), f"only {clean}/{total} cases reproduced in every rounding decision"

@@ -94,6 +94,9 @@ def test_forward_single_quality_parity(gpu_model):
                 total += 1
         per_shape[shape] = c
     print(f"difference-free cases: {clean}/{total}  per shape {per_shape};  max |bpp_kernel - bpp_oracle| over them: {max(_BPP_ABS):.3e} (absolute)")
+    from conftest import record_measurement
+    record_measurement("end-to-end seeds x qualities x shapes, default profile", difference_free=f"{clean}/{total}",
+                       max_abs_dbpp=f"{max(_BPP_ABS):.3e}")
     assert clean >= min_clean_cases(total), f"only {clean}/{total} cases agree in every rounding decision: {per_shape}"
     # every case is inside conftest.bpp_tol (4 fp32 ulps of the rate; check_bpp_abs above).  How many also meet the north
     # star's 1e-6 ABSOLUTE depends on the host CPU's erfc (54 % ... 85 % across the boxes of round 3, at 20-31 bpp where
@@ -101,6 +104,8 @@ def test_forward_single_quality_parity(gpu_model):
     within = sum(d <= BPP_ABS_TARGET for d in _BPP_ABS) / len(_BPP_ABS)
     one_ulp = sum(d <= max(BPP_ABS_TARGET, 2.0 ** -23 * r) for d, r in zip(_BPP_ABS, _BPP_RATE)) / len(_BPP_ABS)
     print(f"|dbpp| <= 1e-6 absolute in {within:.0%} of the difference-free cases; within one fp32 ulp of the rate in {one_ulp:.0%}")
+    from conftest import record_measurement
+    record_measurement("rate of the default profile (20-31 bpp)", within_1e_6_abs=f"{within:.0%}", within_one_fp32_ulp=f"{one_ulp:.0%}")
     assert one_ulp >= 0.9
 
 
