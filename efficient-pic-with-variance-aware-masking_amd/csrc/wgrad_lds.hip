@@ -64,12 +64,14 @@ __device__ __forceinline__ void w2_split4(const u32x4 v, uint2 (&pl)[3]) {
   pl[2] = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
 }
 
-template <int KW, int STRIDE, int WN, int WC, int W2_KP>
+template <int KW, int STRIDE, int WN, int WC, int W2_KP, int TN = 1, int TC = 1>
 __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int W2_NB = 32 * WN, W2_CB = 32 * WC, W2_NT = 64 * WN * WC;
+  // a wave owns TN x TC blocks of 32 x 32 (1 x 1 for the k3 / k5 layers, whose kw taps already give it kw block products
+  // per dY fragment; 2 x 1 / 1 x 2 / 2 x 2 for the 1x1 layers, which have one tap)
+  constexpr int W2_NB = 32 * WN * TN, W2_CB = 32 * WC * TC, W2_NT = 64 * WN * WC;
   constexpr int LGKP = W2_KP == 64 ? 6 : 5;                   // chunk = 64 or 32 output pixels
-  constexpr int W2_SY_BYTES = WN * 3 * W2_KP * 64;
+  constexpr int W2_SY_BYTES = (W2_NB / 32) * 3 * W2_KP * 64;
   constexpr int UY = W2_NB / 4, UX = W2_CB / 4;               // 16-byte units per pixel of the dY / input tile
   constexpr int PY = W2_NT / UY, PX = W2_NT / UX;             // pixels one pass of the workgroup stages (8 WC, 8 WN)
   constexpr int NYU = (W2_KP + PY - 1) / PY;                  // passes over the 64 dY pixels
@@ -184,19 +186,23 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
     }
   };
 
-  // ---- compute roles: wave = one 32 x 32 block of the tile, all KW taps
-  const int nb = wid % WN, cb = wid / WN;
+  // ---- compute roles: wave = TN x TC blocks of 32 x 32 of the tile, all KW taps
+  const int nb0 = (wid % WN) * TN, cb0 = (wid / WN) * TC;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   // transposed read: lane 4 q + p of 16-lane group g supplies pixel row q, channels 16 (g & 1) + 4 p .. + 3; the group
   // receives pixels 8 (g >> 1) + 4 h + {0..3} of channel 16 (g & 1) + (lane & 15)
   const unsigned lane_off = (unsigned)((8 * (g >> 1) + qq) * 64 + (16 * (g & 1) + 4 * pp) * 2);
-  const unsigned a_base = lane_off + (unsigned)(nb * 3 * W2_KP * 64);
-  const unsigned b_base = lane_off + (unsigned)(cb * 3 * XPL * 64);
-  f32x16 acc[KW];
+  const unsigned a_base = lane_off + (unsigned)(nb0 * 3 * W2_KP * 64);
+  const unsigned b_base = lane_off + (unsigned)(cb0 * 3 * XPL * 64);
+  f32x16 acc[TN][TC][KW];
 #pragma unroll
-  for (int t = 0; t < KW; ++t)
+  for (int u = 0; u < TN; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int v = 0; v < TC; ++v)
+#pragma unroll
+      for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][v][t][r] = 0.f;
 
   auto tr8 = [&](const unsigned char* base, unsigned off) -> bf16x8 {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -211,30 +217,38 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
 #pragma unroll
     for (int ks = 0; ks < W2_KP / 16; ++ks) {
       const int r = (ks * 16) >> lg, oxs = (ks * 16) & (SEGW - 1);
-      bf16x8 fa[3];
+      bf16x8 fa[TN][3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) fa[k] = tr8(sY, a_base + (unsigned)((k * W2_KP + ks * 16) * 64));
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fa[u][k] = tr8(sY, a_base + (unsigned)(((u * 3 + k) * W2_KP + ks * 16) * 64));
       const unsigned row = (unsigned)(r * XWL + oxs);
 #pragma unroll
       for (int t = 0; t < KW; ++t) {
         const unsigned px = row + (STRIDE == 2 ? (unsigned)((t & 1) * XWH + (t >> 1)) : (unsigned)t);
-        bf16x8 fb[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fb[k] = tr8(sX, b_base + (unsigned)(k * XPL * 64) + px * 64u);
-        // smallest terms first, as in the convolution kernel: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[t], 0, 0, 0);
+        for (int v = 0; v < TC; ++v) {
+          bf16x8 fb[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) fb[k] = tr8(sX, b_base + (unsigned)((v * 3 + k) * XPL * 64) + px * 64u);
+#pragma unroll
+          for (int u = 0; u < TN; ++u) {
+            // smallest terms first, as in the convolution kernel: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[2], acc[u][v][t], 0, 0, 0);
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][2], fb[0], acc[u][v][t], 0, 0, 0);
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][1], fb[1], acc[u][v][t], 0, 0, 0);
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[1], acc[u][v][t], 0, 0, 0);
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][1], fb[0], acc[u][v][t], 0, 0, 0);
+            acc[u][v][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][0], fb[0], acc[u][v][t], 0, 0, 0);
+          }
+        }
       }
     }
   };
 
   // LDS slots the loader never writes must read as zero: pixel slots of the de-interleaved rows beyond XW
   if (STRIDE == 2) {
-    for (int i = tid; i < WC * 3 * XPL * 4; i += W2_NT) reinterpret_cast<uint4*>(sX)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (W2_CB / 32) * 3 * XPL * 4; i += W2_NT) reinterpret_cast<uint4*>(sX)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
   if (q_begin < q_end) {
@@ -255,19 +269,24 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
   const int taps = KW * KW;
   float* part = S > 1 ? pr.workspace + (size_t)split * ((size_t)N * C * taps + N) : nullptr;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int c = c0 + 32 * cb + l31;
 #pragma unroll
-  for (int t = 0; t < KW; ++t) {
-    const int tap = ty * KW + t;
+  for (int u = 0; u < TN; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (n < N && c < C) {
-        if (part) part[((size_t)n * C + c) * taps + tap] = acc[t][r];
-        else pr.dw[((size_t)n * pr.cin_total + pr.c_off + c) * taps + tap] = acc[t][r];
+    for (int v = 0; v < TC; ++v) {
+      const int c = c0 + 32 * (cb0 + v) + l31;
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const int tap = ty * KW + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + 32 * (nb0 + u) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n < N && c < C) {
+            if (part) part[((size_t)n * C + c) * taps + tap] = acc[u][v][t][r];
+            else pr.dw[((size_t)n * pr.cin_total + pr.c_off + c) * taps + tap] = acc[u][v][t][r];
+          }
+        }
       }
     }
-  }
   if (want_db) {                                                // block-uniform
     float* red = reinterpret_cast<float*>(smem);                // [PY pixel groups][NB channels]; the tiles are dead
 #pragma unroll
@@ -283,8 +302,8 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
   }
 }
 
-static size_t w2_lds_bytes(int kw, int stride, int wn, int wc, int kp) {
-  return (size_t)wn * 3 * kp * 64 + (size_t)wc * 3 * w2_xp_max(kw, stride, kp) * 64;
+static size_t w2_lds_bytes(int kw, int stride, int nbk, int cbk, int kp) {      // nbk / cbk: 32-channel blocks of the tile
+  return (size_t)nbk * 3 * kp * 64 + (size_t)cbk * 3 * w2_xp_max(kw, stride, kp) * 64;
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -294,7 +313,8 @@ bool wgrad2_eligible(const vam_wgrad& p) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("VAMPIC_WGRAD_LDS"); on = (e && e[0] == '0') ? 0 : 1; }
   if (!on) return false;
-  if (!((p.kh == 3 || p.kh == 5) && p.kw == p.kh)) return false;
+  if (!((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh)) return false;
+  if (p.kh == 1 && p.stride == 2) return false;
   const int stride = p.stride == 2 ? 2 : 1;
   if (!(p.W == 16 || p.W == 32 || (p.W >= 64 && p.W % 64 == 0))) return false;
   if (((long)p.H * p.W) % 64 != 0) return false;
@@ -307,35 +327,50 @@ bool wgrad2_eligible(const vam_wgrad& p) {
   return true;
 }
 
-// wave grid of a problem: the candidate with the least padded work (ties: the larger tile, less re-staging)
-struct W2Tile { int wn, wc, kp; };
-static const W2Tile w2_tiles[] = {{4, 2, 64}, {3, 2, 64}, {2, 2, 64}, {4, 1, 64}, {3, 3, 64}};
+// tile of a problem: the candidate with the least padded work (ties: the larger tile, less re-staging)
+struct W2Tile { int wn, wc, tn, tc, kp; int nb() const { return 32 * wn * tn; } int cb() const { return 32 * wc * tc; } };
+static const W2Tile w2_tiles_k35[] = {{4, 2, 1, 1, 64}, {3, 2, 1, 1, 64}, {2, 2, 1, 1, 64}, {4, 1, 1, 1, 64}, {3, 3, 1, 1, 64}};
+static const W2Tile w2_tiles_k1[] = {{3, 2, 2, 1, 32}, {3, 2, 1, 2, 32}, {2, 2, 2, 2, 32}};
 static int w2_force_kp() {                                      // VAMPIC_WGRAD_KP=32|64: chunk size (measurements)
   static int kp = -1;
   if (kp < 0) { const char* e = getenv("VAMPIC_WGRAD_KP"); kp = e ? atoi(e) : 0; }
   return kp == 32 || kp == 64 ? kp : 0;
 }
 W2Tile wgrad2_tile(const vam_wgrad& p) {
-  static int fn = -1, fc = -1;                                  // VAMPIC_WGRAD_TILE="wn,wc": force one grid (measurements)
+  static int fn = -1, fc = -1;                                  // VAMPIC_WGRAD_TILE="wn,wc": force one wave grid (measurements; k3 / k5)
   if (fn < 0) {
     fn = fc = 0;
     if (const char* e = getenv("VAMPIC_WGRAD_TILE")) sscanf(e, "%d,%d", &fn, &fc);
   }
-  // stride-2 layers stage (2 SEGW + kw) input pixels per row: 32-pixel chunks keep two workgroups per CU
-  const int kp = w2_force_kp() ? w2_force_kp() : (p.stride == 2 ? 32 : 64);
-  if (fn > 0)
-    for (const W2Tile& t : w2_tiles)
-      if (t.wn == fn && t.wc == fc) return W2Tile{t.wn, t.wc, kp};
-  W2Tile best = w2_tiles[0];
-  double best_cost = 1e300;
-  for (const W2Tile& t : w2_tiles) {
-    if (t.wn == 3 && t.wc == 3) continue;                       // nine-wave blocks: measured, not chosen automatically
-    const double area = (double)cdiv(p.N, 32 * t.wn) * 32 * t.wn * cdiv(p.C, 32 * t.wc) * 32 * t.wc;
-    const double cost = area * (1.0 + 0.02 * (8 - t.wn * t.wc));     // mild preference for the larger tiles
-    if (cost < best_cost) { best_cost = cost; best = t; }
+  if (p.kh == 1) {
+    W2Tile best = w2_tiles_k1[0];
+    double best_cost = 1e300;
+    for (const W2Tile& t : w2_tiles_k1) {
+      const double cost = (double)cdiv(p.N, t.nb()) * t.nb() * cdiv(p.C, t.cb()) * t.cb() * (t.tn * t.tc == 4 ? 0.97 : 1.0);
+      if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
   }
-  best.kp = kp;
-  return best;
+  // Measured choice (scratch/r4_run4.sh: every wave grid x chunk size forced over the k3 / k5 shapes of a first_train step,
+  // profiles/r04_wgrad_tile_sweep.txt; TF/s): small tiles with 32-pixel chunks win almost everywhere — their LDS footprint
+  // (25 - 40 KB) keeps three or four workgroups on a CU, whose staging phases and barriers then overlap (occupancy beats
+  // operand reuse on this chip, as in the convolution kernel): 2 x 2 waves, 64 x 64 tile is the default;
+  //   C <= 32 (the 16-channel first / last layers, the 32-channel support segments): 4 x 1 waves, 128 x 32 tile — half or
+  //     three quarters of a 64-column tile would be padding;
+  //   N a multiple of 96 with few n tiles (96 -> 96 of the residual units): 3 x 2 waves, 96 x 64 tile;
+  //   k5 stride 2 below 65536 output pixels: 4 x 2 waves with 64-pixel chunks (the 2 SEGW + 5 input pixels per row make
+  //     32-pixel chunks pay two staging rounds per MFMA block there: 136 vs 119 TF/s).
+  const int fkp = w2_force_kp();
+  if (fn > 0)
+    for (const W2Tile& t : w2_tiles_k35)
+      if (t.wn == fn && t.wc == fc) return W2Tile{t.wn, t.wc, 1, 1, fkp ? fkp : (p.stride == 2 ? 32 : 64)};
+  const long P = (long)p.B * p.H * p.W;
+  W2Tile t{2, 2, 1, 1, 32};
+  if (p.C <= 32) t = W2Tile{4, 1, 1, 1, 32};
+  else if (p.stride == 2 && p.kh == 5 && P < 65536) t = W2Tile{4, 2, 1, 1, 64};
+  else if (p.N % 96 == 0 && p.N <= 96) t = W2Tile{3, 2, 1, 1, 32};
+  if (fkp) t.kp = fkp;
+  return t;
 }
 
 int wgrad2_splits(const vam_wgrad& p) {
@@ -345,16 +380,16 @@ int wgrad2_splits(const vam_wgrad& p) {
   // 17 splits do not), plus what a split costs: its partial tile is written once and read back by the reduce kernel.
   const W2Tile t = wgrad2_tile(p);
   const int stride = p.stride == 2 ? 2 : 1;
-  const long per = (long)p.kh * cdiv(p.N, 32 * t.wn) * cdiv(p.C, 32 * t.wc);
+  const long per = (long)p.kh * cdiv(p.N, t.nb()) * cdiv(p.C, t.cb());
   const long chunks = ((long)p.B * p.H * p.W) / t.kp;
-  const size_t lds = w2_lds_bytes(p.kh, stride, t.wn, t.wc, t.kp);
+  const size_t lds = w2_lds_bytes(p.kh, stride, t.nb() / 32, t.cb() / 32, t.kp);
   long wg_per_cu = (long)(160 * 1024 / lds);
   const long by_waves = 16 / (t.wn * t.wc);                     // four waves per SIMD at most for these register counts
   if (wg_per_cu > by_waves) wg_per_cu = by_waves;
   if (wg_per_cu < 1) wg_per_cu = 1;
   const long slots = 256 * wg_per_cu;                           // MI355X: 256 CUs
-  const long min_chunks = 1024 / t.kp;                          // at least 1024 pixels per split
-  long cap = chunks / min_chunks;
+  const long min_chunks = 256 / t.kp;                           // at least 256 pixels per split (small layers are latency-bound:
+  long cap = chunks / min_chunks;                               //  16 chunks in a row on 24 workgroups took 65 us for 0.6 GFLOP)
   if (cap > 256) cap = 256;
   long best_s = 1;
   double best_cost = 1e300;
@@ -367,15 +402,15 @@ int wgrad2_splits(const vam_wgrad& p) {
   return (int)best_s;
 }
 
-template <int KW, int STRIDE, int WN, int WC, int KP>
+template <int KW, int STRIDE, int WN, int WC, int KP, int TN = 1, int TC = 1>
 static int w2_launch(const Wgrad2Args& a, int max_blocks, int n_sub, hipStream_t s) {
   static bool attr = false;
-  const size_t lds = w2_lds_bytes(KW, STRIDE, WN, WC, KP);
+  const size_t lds = w2_lds_bytes(KW, STRIDE, WN * TN, WC * TC, KP);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE, WN, WC, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE, WN, WC, KP>), dim3(max_blocks, n_sub), dim3(64 * WN * WC), lds, s, a);
+  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC>), dim3(max_blocks, n_sub), dim3(64 * WN * WC), lds, s, a);
   return check_launch("wgrad2_kernel");
 }
 
@@ -389,7 +424,7 @@ static int w2_launch_ks(int kw, int st, int kp, const Wgrad2Args& a, int max_blo
   return kp == 32 ? w2_launch<5, 2, WN, WC, 32>(a, max_blocks, n, stream) : w2_launch<5, 2, WN, WC, 64>(a, max_blocks, n, stream);
 }
 
-// eligible problems of one (kernel size, stride) class: one launch per wave grid
+// eligible problems of one (kernel size, stride) class: one launch per tile shape
 int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
   bool done[VAM_MAX_WGRAD_GROUP] = {};
   const int kw = probs[0].kh, st = probs[0].stride == 2 ? 2 : 1;
@@ -401,16 +436,20 @@ int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
     for (int i = i0; i < n; ++i) {
       if (done[i]) continue;
       const W2Tile ti = wgrad2_tile(probs[i]);
-      if (ti.wn != t.wn || ti.wc != t.wc || ti.kp != t.kp) continue;
+      if (ti.wn != t.wn || ti.wc != t.wc || ti.kp != t.kp || ti.tn != t.tn || ti.tc != t.tc) continue;
       done[i] = true;
       const vam_wgrad& p = probs[i];
       a.p[n_sub++] = p;
       const int S = p.splits > 1 ? p.splits : 1;
-      const int nb = p.kh * cdiv(p.N, 32 * t.wn) * cdiv(p.C, 32 * t.wc) * S;
+      const int nb = p.kh * cdiv(p.N, t.nb()) * cdiv(p.C, t.cb()) * S;
       max_blocks = nb > max_blocks ? nb : max_blocks;
     }
     int rc;
-    if (t.wn == 4 && t.wc == 2) rc = w2_launch_ks<4, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
+    if (kw == 1) {
+      if (t.tn == 2 && t.tc == 1) rc = w2_launch<1, 1, 3, 2, 32, 2, 1>(a, max_blocks, n_sub, stream);
+      else if (t.tn == 1 && t.tc == 2) rc = w2_launch<1, 1, 3, 2, 32, 1, 2>(a, max_blocks, n_sub, stream);
+      else rc = w2_launch<1, 1, 2, 2, 32, 2, 2>(a, max_blocks, n_sub, stream);
+    } else if (t.wn == 4 && t.wc == 2) rc = w2_launch_ks<4, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
     else if (t.wn == 3 && t.wc == 2) rc = w2_launch_ks<3, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
     else if (t.wn == 2 && t.wc == 2) rc = w2_launch_ks<2, 2>(kw, st, t.kp, a, max_blocks, n_sub, stream);
     else if (t.wn == 4 && t.wc == 1) rc = w2_launch_ks<4, 1>(kw, st, t.kp, a, max_blocks, n_sub, stream);

@@ -31,6 +31,11 @@ CASES = [
     (3, 2, (64,), 64, (16, 16), 2),             # k3 stride 2
     (5, 1, (32,), 64, (16, 32), 2),             # k5 stride 1
     (3, 1, (64,), 64, (16, 16), 40),            # 10240 pixels: pixel splits + reduce
+    (1, 1, (192,), 192, (64, 64), 1),           # 1x1 layers: waves own 2 x 1 / 1 x 2 / 2 x 2 blocks, 32-pixel chunks
+    (1, 1, (96,), 192, (16, 16), 4),
+    (1, 1, (192,), 96, (32, 32), 2),
+    (1, 1, (160, 32), 320, (16, 16), 2),
+    (1, 1, (192,), 576, (16, 16), 12),          # 3072 pixels: splits
 ]
 
 
@@ -49,7 +54,7 @@ def test_lds_wgrad_matches_autograd(k, stride, segs, n, hw, B):
     dw = torch.full((n, cin, k, k), float("nan"), device="cuda")
     db = torch.full((n,), float("nan"), device="cuda")
     probs = ops.wgrad_problems(xv, dyv, dw, db, stride=stride)
-    if B * H * W >= 4096:
+    if B * H * W >= 8192:
         assert probs[0].splits > 1
     ops.wgrad_group(probs)
     torch.cuda.synchronize()
@@ -66,7 +71,7 @@ def test_mixed_group_routes_each_problem_to_its_kernel():
     (register-gather kernel): every problem gets its own result."""
     out = []
     probs = []
-    for (k, hw, c, n) in [(3, (16, 16), 64, 64), (3, (8, 8), 64, 64), (1, (16, 16), 96, 192)]:
+    for (k, hw, c, n) in [(3, (16, 16), 64, 64), (3, (8, 8), 64, 64), (1, (16, 16), 96, 192), (1, (8, 8), 96, 192)]:
         x = synth.normal((2, c, *hw), 11 + k + hw[0])
         dy = synth.normal((2, n, *hw), 12 + k + hw[0])
         w = synth.normal((n, c, k, k), 1, 0.1).requires_grad_(True)

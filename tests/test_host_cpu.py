@@ -211,7 +211,7 @@ def test_weight_gradient_planning_is_host_arithmetic():
     """``vam_conv_wgrad_plan`` (pixel splits + workspace of a weight-gradient problem) is pure host arithmetic on the
     problem's extents: callable without a GPU, deterministic, and consistent with what the launch will need —
     workspace = splits x (N C taps + N) floats, no split for problems that already fill the chip, never more splits
-    than 1024-pixel ranges.  (The tile the kernel picks — 96x64 where N is a multiple of 96 and C >= 64 — enters through
+    than 256-pixel ranges.  (The tile the kernel picks — 96x64 where N is a multiple of 96 and C >= 64 — enters through
     the number of weight tiles.)"""
     import ctypes
     lib = L.load()
@@ -228,7 +228,7 @@ def test_weight_gradient_planning_is_host_arithmetic():
         B, H, W, C_, N, k = shape
         s, nb = plan(*shape)
         assert (s, nb) == plan(*shape)
-        assert 1 <= s <= 256 and s <= max(1, B * H * W // 1024), shape      # >= 1024 pixels per split (LDS-tiled kernel; 2048: wgrad_kernel)
+        assert 1 <= s <= 256 and s <= max(1, B * H * W // 256), shape       # >= 256 pixels per split (LDS-tiled kernel; 2048: wgrad_kernel)
         assert nb == (0 if s == 1 else s * (N * C_ * k * k + N) * 4), shape
     assert plan(1, 16, 16, 64, 32, 3)[0] == 1                      # 256 pixels: nothing to split
     assert plan(32, 128, 128, 192, 192, 1)[0] > 8                  # a 1x1 layer on 524288 pixels has 2 x 3 weight tiles
