@@ -397,6 +397,7 @@ def main():
             line["bf16"] = bf16_rec
         if train_rec is not None:
             line["train"] = train_rec
+        line["retired_graphs"] = ops.retired_graphs()      # executable graphs kept alive instead of destroyed (ops.Graph docstring)
         if forced:
             line["collectives"] = "forced (1-rank nccl group: barrier + max-over-ranks all-reduce issued on RCCL)"
         if world == 1 and not a.no_cpu_baseline:

@@ -15,7 +15,7 @@ VAM_MAX_SEG = 4
 VAM_MAX_GROUP = 8
 
 # enum vam_act
-ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQRT, ACT_SQRT = range(8)
+ACT_NONE, ACT_GELU, ACT_LEAKY, ACT_HALF_TANH, ACT_SIGMOID, ACT_CLAMP01, ACT_RSQRT, ACT_SQRT, ACT_DOUBLE = range(9)
 # enum vam_conv_flags
 CONV_SQUARE_IN, CONV_PS2, CONV_OUT_NCHW, CONV_IN_BF3, CONV_OUT_BF3 = 1, 2, 4, 8, 16
 CONV_W_BF16, CONV_IN_BF16, CONV_OUT_BF16, CONV_AUX_BF16 = 32, 64, 128, 256      # bf16-storage mode (BASELINE configs[2])
@@ -44,7 +44,7 @@ class VamWgrad(C.Structure):
                 ("ld_x", C.c_int), ("ld_dy", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("C", C.c_int), ("N", C.c_int),
                 ("cin_total", C.c_int), ("c_off", C.c_int), ("stride", C.c_int), ("Hx", C.c_int), ("Wx", C.c_int),
-                ("splits", C.c_int), ("workspace", C.c_void_p)]
+                ("splits", C.c_int), ("workspace", C.c_void_p), ("slot_share", C.c_float), ("pad_", C.c_int32)]
 
 
 class VamAux(C.Structure):

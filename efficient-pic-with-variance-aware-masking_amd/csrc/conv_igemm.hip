@@ -87,6 +87,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case VAM_ACT_CLAMP01: return fminf(fmaxf(v, 0.f), 1.f);
     case VAM_ACT_RSQRT: return 1.0f / sqrtf(v);
     case VAM_ACT_SQRT: return sqrtf(v);
+    case VAM_ACT_DOUBLE: return 2.0f * v;
     default: return v;
   }
 }

@@ -387,16 +387,25 @@ int wgrad2_splits(const vam_wgrad& p) {
   const long by_waves = 16 / (t.wn * t.wc);                     // four waves per SIMD at most for these register counts
   if (wg_per_cu > by_waves) wg_per_cu = by_waves;
   if (wg_per_cu < 1) wg_per_cu = 1;
-  const long slots = 256 * wg_per_cu;                           // MI355X: 256 CUs
-  const long min_chunks = 256 / t.kp;                           // at least 256 pixels per split (small layers are latency-bound:
-  long cap = chunks / min_chunks;                               //  16 chunks in a row on 24 workgroups took 65 us for 0.6 GFLOP)
+  long slots = 256 * wg_per_cu;                                 // MI355X: 256 CUs
+  if (p.slot_share > 0.f && p.slot_share < 1.f) {               // the problem shares its launch with others
+    slots = (long)(slots * (double)p.slot_share + 0.5);
+    if (slots < 1) slots = 1;
+  }
+  const long min_chunks = 256 / t.kp;                           // at least 256 pixels per split
+  long cap = chunks / min_chunks;
   if (cap > 256) cap = 256;
+  // time in chunk units: rounds x (a workgroup's fixed cost [descriptors, first loads, its partial tile] + its chunks) + what
+  // a split adds beyond that (the reduce kernel reads every partial tile back).  Calibrated on 6x[320 -> 224 k3] at 8192
+  // pixels: 8 splits 491 us, 16 splits 648 us.
+  // (1x1 layers: a chunk is a third of a k3 chunk's work and the partial tile a third of its bytes, while the fixed cost is
+  // the same — more, cheaper splits: 2 weight tiles x 64 splits left half of the CUs idle on the 96-channel layers)
+  const double t_fix = (p.kh == 1 ? 10.0 : 6.0) * 32 / t.kp, t_split = (p.kh == 1 ? 0.3 : 1.0) * 32 / t.kp;
   long best_s = 1;
   double best_cost = 1e300;
   for (long s = 1; s <= (cap < 1 ? 1 : cap); ++s) {
     const double rounds = (double)((per * s + slots - 1) / slots);
-    const double work = rounds * (double)((chunks + s - 1) / s);
-    const double cost = work + (s > 1 ? 0.25 * s * (64.0 / t.kp) : 0.0);    // one partial tile ~ a quarter of a 64-pixel chunk's time
+    const double cost = rounds * (t_fix + (double)((chunks + s - 1) / s)) + (s > 1 ? t_split * s : 0.0);
     if (cost < best_cost - 1e-9) { best_cost = cost; best_s = s; }
   }
   return (int)best_s;

@@ -200,10 +200,12 @@ class Plan:
         lib = L.load()
         for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
             chunk = list(problems[i:i + L.VAM_MAX_WGRAD_GROUP])
+            if len(chunk) > 1:
+                ops.wgrad_plan(chunk)         # pixel splits against each problem's share of the grouped launch
             arr = (L.VamWgrad * len(chunk))(*chunk)
             n = len(chunk)
             self.keep.append(arr)
-            self.keep += [c._ws for c in chunk if getattr(c, "_ws", None) is not None]     # pixel-split scratch (ops.wgrad_problems)
+            self.keep += [c._ws for c in chunk if getattr(c, "_ws", None) is not None]     # pixel-split scratch (ops.wgrad_plan)
             fl = sum(2.0 * c.B * c.H * c.W * c.C * c.N * c.kh * c.kw for c in chunk)
             self.flops += fl
             self.meta.append({"kind": "wgrad", "flops": fl, "desc": f"{n}x wgrad [{chunk[0].C}->{chunk[0].N} k{chunk[0].kh}]"})

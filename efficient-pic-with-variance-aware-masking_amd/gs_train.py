@@ -250,10 +250,11 @@ def _deconv_fwd(plan, pk, m: Ly.ConvTranspose2d, x: View, tape: list, out_nchw: 
 
 
 def _gdn_fwd(plan, pk, g: Ly.GDN, x: View, tape: list) -> View:
-    n = plan.buf(x.B, x.H, x.W, x.C)
-    plan.conv([ops.conv_problem(pk.f[id(g)], [x], n, L.ACT_NONE, flags=L.CONV_SQUARE_IN)])
-    y = plan.buf(x.B, x.H, x.W, x.C)
-    plan.call(lambda: ops.ew(L.EW_GDN_APPLY, [x, n], [y], flag=1 if g.inverse else 0), "gdn apply")
+    # one launch, as the eval plans: y = x * rsqrt(norm) (sqrt: inverse) in the epilogue; the norm pool itself — what the
+    # backward needs — leaves as the second output
+    n, y = plan.buf(x.B, x.H, x.W, x.C), plan.buf(x.B, x.H, x.W, x.C)
+    plan.conv([ops.conv_problem(pk.f[id(g)], [x], y, L.ACT_SQRT if g.inverse else L.ACT_RSQRT, mul=x, flags=L.CONV_SQUARE_IN,
+                                preact=n)])
     tape.append(dict(kind="gdn", mod=g, x=x, n=n))
     return y
 
@@ -368,10 +369,8 @@ def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
     x, n = r["x"], r["n"]
     s, dx0, x2 = (bw.buf(x.B, x.H, x.W, x.C) for _ in range(3))
     bw.call(lambda: ops.ew(L.EW_GDN_BWD_PREP, [x, n, dy], [s, dx0, x2], flag=1 if g.inverse else 0), "gdn bwd prep")
-    u = bw.buf(x.B, x.H, x.W, x.C)
-    bw.conv([ops.conv_problem(pk.d[id(g)], [s], u)])
-    dx = bw.buf(x.B, x.H, x.W, x.C)
-    bw.call(lambda: ops.ew(L.EW_GDN_BWD_FIN, [dx0, x, u], [dx]), "gdn bwd fin")
+    dx = bw.buf(x.B, x.H, x.W, x.C)                    # dx = dx0 + x * 2 (gamma'^T dL/dnorm): the sum in the launch's epilogue
+    bw.conv([ops.conv_problem(pk.d[id(g)], [s], dx, L.ACT_DOUBLE, mul=x, post=dx0)])
     C_ = x.C
     tg = torch.zeros((C_, C_), dtype=torch.float32, device=x.buf.device)
     tb = torch.zeros((C_,), dtype=torch.float32, device=x.buf.device)

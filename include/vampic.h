@@ -49,7 +49,9 @@ enum vam_act {
   VAM_ACT_SIGMOID = 4,   /*                                    (layers/layers.py:72)*/
   VAM_ACT_CLAMP01 = 5,   /* clamp_(0,1)                        (pic.py:558,651)     */
   VAM_ACT_RSQRT = 6,     /* GDN   (layers/gdn.py:72)                                */
-  VAM_ACT_SQRT = 7       /* IGDN  (layers/gdn.py:70)                                */
+  VAM_ACT_SQRT = 7,      /* IGDN  (layers/gdn.py:70)                                */
+  VAM_ACT_DOUBLE = 8     /* 2 v: GDN backward, dx = dy dy/dx|norm + x * 2 (gamma'^T dL/dnorm) in one launch
+                            (autograd of layers/gdn.py:62-75; exact: a power-of-two factor)  */
 };
 
 enum vam_conv_flags {
@@ -348,6 +350,8 @@ typedef struct vam_wgrad {
   int splits;         /* 0 / 1: one block per weight tile walks all pixels.  > 1 (from vam_conv_wgrad_plan): the      */
   float* workspace;   /* pixels are cut into `splits` ranges whose partial tiles go to this caller-owned buffer and   */
                       /* are added in range order by a second launch (layers with few weight tiles and many pixels)  */
+  float slot_share;   /* planning hint (vam_conv_wgrad_plan only): the fraction of the chip this problem can count on  */
+  int32_t pad_;       /* when it shares a grouped launch with others (its share of the group's FLOPs); 0 = alone       */
 } vam_wgrad;
 /* Suggested number of pixel splits for a problem (>= 1) and the workspace it needs (0 bytes when 1). */
 int vam_conv_wgrad_plan(const vam_wgrad* problem, size_t* workspace_bytes);
