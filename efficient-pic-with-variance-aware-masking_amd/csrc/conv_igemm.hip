@@ -70,6 +70,7 @@ struct ConvP {
 
 constexpr int VAM_CONVI_DUAL = 1 << 29;     // internal ConvP flag: 16-channel input, two taps share one 32-channel K chunk (split-operand mode)
 constexpr int VAM_CONVI_STAGED = 1 << 30;   // internal ConvP flag: tensor extents beyond the direct epilogue's 32-bit window
+constexpr int VAM_CONVI_NT = 1 << 28;       // internal ConvP flag: non-temporal stores in the direct epilogue (VAMPIC_NT_STORE=1: experiment)
 
 struct GroupArgs {
   int nprob;
@@ -1104,6 +1105,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const __amdgpu_buffer_rsrc_t r_preact = desc(P.preact);
     const unsigned u_ldpreact = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_preact);
     const int u_act = __builtin_amdgcn_readfirstlane(P.act);
+    const bool nt_store = (__builtin_amdgcn_readfirstlane(P.flags) & VAM_CONVI_NT) != 0;
     const bool full_rows = m0 + BM <= P.P;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1188,8 +1190,13 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
             for (int r = 0; r < 16; ++r)
               if (full_rows || pix4[r] != 0xFFFFFFFFu) omax = fmaxf(omax, fabsf(v[r]));
           }
+          if (nt_store) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 2);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
+          }
         }
       }
     }
@@ -1736,6 +1743,11 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
                                   (((uintptr_t)c.preact.ptr) & 15) == 0 && c.preact.ld >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N)),
                 "conv[%d]: preact is an fp32 NHWC tensor indexed like the output (16-byte aligned, ld %% 4 == 0, ld >= channels)", i);
     p.preact = const_cast<float*>(c.preact.ptr); p.ld_preact = c.preact.ld;
+    {
+      static int nt = -1;                // VAMPIC_NT_STORE=1: outputs of 64 MB or more leave the direct epilogue with non-temporal stores
+      if (nt < 0) { const char* e = getenv("VAMPIC_NT_STORE"); nt = (e && e[0] == '1') ? 1 : 0; }
+      if (nt && (double)c.B * c.Hf * c.Wf * c.ldo * 4.0 >= 64.0 * 1024 * 1024) p.flags |= VAM_CONVI_NT;
+    }
     p.pre = c.pre.ptr; p.ld_pre = c.pre.ld;
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;

@@ -195,8 +195,29 @@ class Plan:
             self.class_of.append(self.cur_class)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_resunit_group(arr, n, ops.stream_ptr()), "vam_resunit_group"))
 
-    def wgrad(self, problems: Sequence[L.VamWgrad]):
-        """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`)."""
+    # Weight gradients have no consumer inside a backward plan (they land in the flat gradient buffer), and inside one
+    # transform every tensor they read — taped activations, output gradients — is written once.  Between defer_wgrad() and
+    # flush_wgrad() their problems are only collected; the flush issues them grouped by shape (up to 16 per launch): the
+    # six residual units of an attention block then share three launches instead of eighteen, each problem planning its
+    # pixel splits against a sixth of the chip (fewer splits, fewer reduce launches, fuller grids).
+    _wgrad_pending: Optional[list] = None
+
+    def defer_wgrad(self):
+        if self._wgrad_pending is None:
+            self._wgrad_pending = []
+
+    def flush_wgrad(self):
+        pend, self._wgrad_pending = self._wgrad_pending, None
+        if pend:
+            pend.sort(key=lambda c: (c.kh, c.stride == 2, c.N, c.C, c.B * c.H * c.W))
+            self.wgrad(pend, now=True)
+
+    def wgrad(self, problems: Sequence[L.VamWgrad], now: bool = False):
+        """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`).  ``now``: a later step of the plan reads the
+        result (a temporary that is re-indexed / re-parametrised into the gradient): never deferred."""
+        if self._wgrad_pending is not None and not now:
+            self._wgrad_pending += list(problems)
+            return
         lib = L.load()
         for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
             chunk = list(problems[i:i + L.VAM_MAX_WGRAD_GROUP])

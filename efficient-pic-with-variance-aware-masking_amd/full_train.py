@@ -176,7 +176,7 @@ def _conv5_bwd(bw, pk, r: dict, dy: View, grads, keep: list) -> Optional[View]:
         t16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=gw.device)
         g6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=gw.device)
         keep += [t16, g6]
-        bw.wgrad(ops.wgrad_problems([x], dy, t16, gb))
+        bw.wgrad(ops.wgrad_problems([x], dy, t16, gb), now=True)          # t16 is re-indexed into gw right below
 
         def scatter():          # captured step: strided copies between pre-allocated buffers, no temporaries
             g6.view(n, 3, 3, 2, 3, 2).copy_(t16[:, :12].view(n, 2, 2, 3, 3, 3).permute(0, 3, 4, 1, 5, 2))
@@ -191,6 +191,7 @@ def _conv5_bwd(bw, pk, r: dict, dy: View, grads, keep: list) -> Optional[View]:
 
 def lower_g_a_backward(bw: E.Plan, tape: list, d_y: View, pk: G.TransformPacks, grads):
     d: Optional[View] = d_y
+    bw.defer_wgrad()                      # grouped by shape at the end of the transform (engine.Plan.flush_wgrad)
     for r in reversed(tape):
         if r["kind"] == "conv5":
             d = _conv5_bwd(bw, pk, r, d, grads, bw.keep)
@@ -198,6 +199,7 @@ def lower_g_a_backward(bw: E.Plan, tape: list, d_y: View, pk: G.TransformPacks, 
             d = G._gdn_bwd(bw, pk, r, d, grads)
         else:
             d = G._attention_block_bwd(bw, pk, r, d, grads, need_dx=True)
+    bw.flush_wgrad()
 
 
 # ============================================================================= the plan

@@ -353,7 +353,7 @@ def _deconv_bwd(bw, pk, r: dict, dy: View, grads, need_dx: bool = True) -> Optio
         tb = torch.zeros((dy.C,), dtype=torch.float32, device=gw.device)
         wsp = ops.colsum_workspace(dy)
         bw.keep += [tw, tb, wsp]
-        bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2))
+        bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2), now=True)      # tw is un-padded into gw right below
         # (torch.mul(.., 1.0, out=..) instead of a contiguous copy_: an element-wise KERNEL node under graph capture, not a
         # device-to-device memcpy node — see vam_memset_zero for what a non-kernel node did in these graphs)
         bw.call(lambda: (ops.colsum(dy, tb, wsp), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
@@ -375,7 +375,7 @@ def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
     tg = torch.zeros((C_, C_), dtype=torch.float32, device=x.buf.device)
     tb = torch.zeros((C_,), dtype=torch.float32, device=x.buf.device)
     bw.keep += [tg, tb]
-    bw.wgrad(ops.wgrad_problems([x2], s, tg, tb))                     # d gamma' [j][i] = sum dn_j x_i^2 ; d beta' = sum dn
+    bw.wgrad(ops.wgrad_problems([x2], s, tg, tb), now=True)           # d gamma' [j][i] = sum dn_j x_i^2 ; d beta' = sum dn (read right below)
     gg, gbeta = grads[id(g.gamma)], grads[id(g.beta)]
     bw.call(lambda: (ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.gamma.detach()), ops.flat_view(tg)], [ops.flat_view(gg)], coef=_GAMMA_BOUND),
                      ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.beta.detach()), ops.flat_view(tb)], [ops.flat_view(gbeta)], coef=_BETA_BOUND)),
@@ -400,6 +400,7 @@ def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torc
         bw.call(lambda: L.check(L.load().vam_nchw_to_nhwc(g_xhat.data_ptr(), d16.ptr, B, 3, H, W, d16.ld, ops.stream_ptr()), "vam_nchw_to_nhwc"),
                 "NCHW -> NHWC")
     d: Optional[View] = d16
+    bw.defer_wgrad()                      # the transform's weight gradients leave grouped by shape (engine.Plan.flush_wgrad)
     for i, r in enumerate(reversed(tape)):
         first = i == len(tape) - 1
         if r["kind"] == "deconv":
@@ -408,6 +409,7 @@ def lower_g_s_backward(bw: E.Plan, tape: list, x_hat: torch.Tensor, g_xhat: torc
             d = _gdn_bwd(bw, pk, r, d, grads)
         else:
             d = _attention_block_bwd(bw, pk, r, d, grads, need_dx=(not first) or need_input_grad)
+    bw.flush_wgrad()
     return d
 
 
