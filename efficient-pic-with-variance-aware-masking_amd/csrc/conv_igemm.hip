@@ -70,7 +70,6 @@ struct ConvP {
 
 constexpr int VAM_CONVI_DUAL = 1 << 29;     // internal ConvP flag: 16-channel input, two taps share one 32-channel K chunk (split-operand mode)
 constexpr int VAM_CONVI_STAGED = 1 << 30;   // internal ConvP flag: tensor extents beyond the direct epilogue's 32-bit window
-constexpr int VAM_CONVI_NT = 1 << 28;       // internal ConvP flag: non-temporal stores in the direct epilogue (VAMPIC_NT_STORE=1: experiment)
 
 struct GroupArgs {
   int nprob;
@@ -926,7 +925,13 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
   const bool out_p3 = (P.flags & VAM_CONV_OUT_BF3) != 0;     // host guarantees: split mode, vec_ok, no PS2
   const bool out16 = (P.flags & VAM_CONV_OUT_BF16) != 0;     // bf16 NHWC output (ldo counts bf16 elements); host guarantees vec_ok
   const bool aux16 = (P.flags & VAM_CONV_AUX_BF16) != 0;     // pre / mul / post / post2 are bf16 NHWC tensors
+#ifdef VAM_NO_TRAIN_EPILOGUE     // A/B build (scratch/ab_epilogue.sh): the training-only epilogue features compiled out
+  const bool mulg = false;
+#define VAM_PREACT(P) false
+#else
   const bool mulg = (P.flags & VAM_CONV_MUL_GELU_GRAD) != 0; // the mul operand is a GELU's pre-activation z: multiply by gelu'(z)
+#define VAM_PREACT(P) ((P).preact != nullptr)
+#endif
   auto ld_aux = [&](const float* base, size_t off) -> float4 {   // four consecutive channels of an epilogue operand
     if (aux16) {
       const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
@@ -992,7 +997,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         const float4 t4 = ld_aux(P.pre, opix * P.ld_pre + cch);
         v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
       }
-      if (P.preact) *reinterpret_cast<float4*>(P.preact + opix * P.ld_preact + cch) = make_float4(v[0], v[1], v[2], v[3]);
+      if (VAM_PREACT(P)) *reinterpret_cast<float4*>(P.preact + opix * P.ld_preact + cch) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], P.act);
       if (P.mul) {
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
         }
         float x = v[k] + (P.bias ? P.bias[nn] : 0.f);
         if (P.pre) x = x + P.pre[opix * P.ld_pre + cch];
-        if (P.preact) P.preact[opix * P.ld_preact + cch] = x;
+        if (VAM_PREACT(P)) P.preact[opix * P.ld_preact + cch] = x;
         x = apply_act(x, P.act);
         if (P.mul) x = x * (mulg ? vam_gelu_grad(P.mul[opix * P.ld_mul + cch]) : P.mul[opix * P.ld_mul + cch]);
         if (P.post) x = x + P.post[opix * P.ld_post + cch];
@@ -1105,7 +1110,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const __amdgpu_buffer_rsrc_t r_preact = desc(P.preact);
     const unsigned u_ldpreact = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_preact);
     const int u_act = __builtin_amdgcn_readfirstlane(P.act);
-    const bool nt_store = (__builtin_amdgcn_readfirstlane(P.flags) & VAM_CONVI_NT) != 0;
     const bool full_rows = m0 + BM <= P.P;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1152,7 +1156,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += t[r];
           }
-          if (P.preact) {
+          if (VAM_PREACT(P)) {
             const unsigned c4 = (poff * u_ldpreact + cch) << 2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_preact, off(r, u_ldpreact, c4), 0, 0);
@@ -1190,13 +1194,8 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
             for (int r = 0; r < 16; ++r)
               if (full_rows || pix4[r] != 0xFFFFFFFFu) omax = fmaxf(omax, fabsf(v[r]));
           }
-          if (nt_store) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 2);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
-          }
+          for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_out, off(r, u_ldo, c4o), 0, 0);
         }
       }
     }
@@ -1743,11 +1742,6 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
                                   (((uintptr_t)c.preact.ptr) & 15) == 0 && c.preact.ld >= ((c.flags & VAM_CONV_PS2) ? c.Cq : c.N)),
                 "conv[%d]: preact is an fp32 NHWC tensor indexed like the output (16-byte aligned, ld %% 4 == 0, ld >= channels)", i);
     p.preact = const_cast<float*>(c.preact.ptr); p.ld_preact = c.preact.ld;
-    {
-      static int nt = -1;                // VAMPIC_NT_STORE=1: outputs of 64 MB or more leave the direct epilogue with non-temporal stores
-      if (nt < 0) { const char* e = getenv("VAMPIC_NT_STORE"); nt = (e && e[0] == '1') ? 1 : 0; }
-      if (nt && (double)c.B * c.Hf * c.Wf * c.ldo * 4.0 >= 64.0 * 1024 * 1024) p.flags |= VAM_CONVI_NT;
-    }
     p.pre = c.pre.ptr; p.ld_pre = c.pre.ld;
     p.mul = c.mul.ptr; p.ld_mul = c.mul.ld;
     p.post = c.post.ptr; p.ld_post = c.post.ld;

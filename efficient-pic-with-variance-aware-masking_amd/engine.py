@@ -203,7 +203,7 @@ class Plan:
     _wgrad_pending: Optional[list] = None
 
     def defer_wgrad(self):
-        if self._wgrad_pending is None:
+        if self._wgrad_pending is None and os.environ.get("VAMPIC_WGRAD_DEFER", "1") != "0":      # 0: the A/B arm
             self._wgrad_pending = []
 
     def flush_wgrad(self):
