@@ -1070,6 +1070,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     // one is needed, where the staged path below waits for one bias / operand load after the other, slab by slab.
     // Same operations in the same order per element as the staged path: bit-identical results
     // (tests/test_gpu_ops.py::test_direct_and_staged_epilogues_are_bit_identical).
+    // (The training-only epilogue features — second output `preact`, gelu'(mul) — live in the staged path alone: the host
+    // sends problems that use them there.  Compiled into this path they cost the inference step 0.07 ms, interleaved A/B,
+    // gpurun_out/r4_epi*.log.)
     // Kept for the 128x64 one-role tile only, the tile of the short-K, store-bound layers (1x1 convolutions of GDN,
     // residual units and attention, the 16-channel first layer), where it measured 6-17 % faster (scratch/ab_epi*.sh:
     // 4x[96->192 1x1] 250 -> 208 us, 2x[192->192 1x1 @128] 667 -> 596 us).  Elsewhere it measured no better or worse:
@@ -1107,8 +1110,6 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
     const unsigned u_ldo = (unsigned)__builtin_amdgcn_readfirstlane(P.ldo), u_ldpre = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_pre);
     const unsigned u_ldmul = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_mul), u_ldpost = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post);
     const unsigned u_ldpost2 = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_post2);
-    const __amdgpu_buffer_rsrc_t r_preact = desc(P.preact);
-    const unsigned u_ldpreact = (unsigned)__builtin_amdgcn_readfirstlane(P.ld_preact);
     const int u_act = __builtin_amdgcn_readfirstlane(P.act);
     const bool full_rows = m0 + BM <= P.P;
 #pragma unroll
@@ -1156,21 +1157,12 @@ __global__ __launch_bounds__(WGM * WGN * 64 * (SPEC ? 2 : 1), SPEC ? ((BM + BN <
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += t[r];
           }
-          if (VAM_PREACT(P)) {
-            const unsigned c4 = (poff * u_ldpreact + cch) << 2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), r_preact, off(r, u_ldpreact, c4), 0, 0);
-          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], u_act);
           if (P.mul) {
             const unsigned c4 = (poff * u_ldmul + cch) << 2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_mul, off(r, u_ldmul, c4), 0, 0));
-            if (mulg) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) t[r] = vam_gelu_grad(t[r]);
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] *= t[r];
           }
@@ -1736,6 +1728,7 @@ int vam_conv_group(const vam_conv* probs, int nprob, void* stream) {
             fits(c.post.ptr, c.post.ld) && fits(c.post2.ptr, c.post2.ld) && fits(c.preact.ptr, c.preact.ld)))
         p.flags |= VAM_CONVI_STAGED;
     }
+    if (c.preact.ptr || (c.flags & VAM_CONV_MUL_GELU_GRAD)) p.flags |= VAM_CONVI_STAGED;   // features of the staged epilogue only
     VAM_REQUIRE(!(c.flags & VAM_CONV_MUL_GELU_GRAD) || (c.mul.ptr && !(c.flags & VAM_CONV_AUX_BF16)),
                 "conv[%d]: VAM_CONV_MUL_GELU_GRAD needs an fp32 mul operand (the GELU's pre-activation)", i);
     VAM_REQUIRE(!c.preact.ptr || (!(c.flags & (VAM_CONV_OUT_NCHW | VAM_CONV_W_BF16)) && c.preact.ld % 4 == 0 &&

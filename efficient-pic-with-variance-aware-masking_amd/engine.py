@@ -203,7 +203,10 @@ class Plan:
     _wgrad_pending: Optional[list] = None
 
     def defer_wgrad(self):
-        if self._wgrad_pending is None and os.environ.get("VAMPIC_WGRAD_DEFER", "1") != "0":      # 0: the A/B arm
+        # OFF by default: measured SLOWER (interleaved on one box, gpurun_out/r4_defer*.log: first_train 141.9 vs 137.7 ms).
+        # A weight gradient launched right behind the data-gradient launch that produced its dY finds dY in the 256 MB
+        # last-level cache; deferred to the end of the transform, both operands come from HBM.  VAMPIC_WGRAD_DEFER=1 opts in.
+        if self._wgrad_pending is None and os.environ.get("VAMPIC_WGRAD_DEFER", "0") == "1":
             self._wgrad_pending = []
 
     def flush_wgrad(self):
@@ -688,7 +691,7 @@ def lower_rem_blocks_train(plan: Plan, mods, y_cks, ep_bases, ep_progs, atts, ou
     """Forward of K REM blocks (same arithmetic as :func:`lower_rem_blocks`) recording a tape."""
     K = len(mods)
     m0 = mods[0]
-    assert all(m.mu_std for m in mods)
+    assert len({m.mu_std for m in mods}) == 1         # mu_std = False: ep_progs / outs hold the scale alone (rem.py:86,100)
     names = ["enc_base_rep", "enc_progressive_entropy_params", "enc_base_entropy_params"]
     cur = [[y] for y in y_cks] + [list(e) for e in ep_progs] + [list(e) for e in ep_bases]
     tape = {"branch": [], "enc": [], "K": K}
@@ -757,10 +760,12 @@ def lower_rem_backward(plan: Plan, tape: dict, mods, d_mu: Sequence[View], d_sig
     so d ret = d res * att; nothing upstream of the REM inputs is trainable (train.py:223-226)."""
     K = tape["K"]
     N = mods[0].dim_block
-    d_ret = [plan.buf(d_mu[k].B, d_mu[k].H, d_mu[k].W, 2 * N) for k in range(K)]
+    mu_std = mods[0].mu_std                         # False: the block refines the scale only, ret has N channels and dL/dmu stops here
+    d_ret = [plan.buf(d_sigma[k].B, d_sigma[k].H, d_sigma[k].W, (2 if mu_std else 1) * N) for k in range(K)]
     for k in range(K):
-        plan.call(lambda k=k: ops.mul(d_mu[k], atts[k], d_ret[k].window(0, N)), "d ret (mu half)")
-        plan.call(lambda k=k: ops.mul(d_sigma[k], atts[k], d_ret[k].window(N, N)), "d ret (sigma half)")
+        if mu_std:
+            plan.call(lambda k=k: ops.mul(d_mu[k], atts[k], d_ret[k].window(0, N)), "d ret (mu half)")
+        plan.call(lambda k=k: ops.mul(d_sigma[k], atts[k], d_ret[k].window(N if mu_std else 0, N)), "d ret (sigma half)")
     d = d_ret
     for recs in reversed(tape["enc"]):
         d = _rb_backward(plan, recs, d, True, packs, grads)

@@ -639,8 +639,6 @@ class VarianceMaskingPICREM(VarianceMaskingPIC):
             raise NotImplementedError()
         L.require_gpu()
         self._check_config()
-        if not self.mu_std:
-            raise NotImplementedError("the REM lowering is built for mu_std=True (README config)")
         own = isinstance(checkpoint_ref, str)
         if checkpoint_ref is not None and not own:
             checkpoint_ref = checkpoint_ref.detach()
@@ -955,8 +953,8 @@ class _FsqPlan:
         y_sub = y.window(0, d) if m.delta_encode else None                        # pic.py:583-584
         yp = self.y_prog = plan.buf(B, h, w, d)
         g_s = m.g_s[1] if m.multiple_decoder else m.g_s
-        if train and not (m.all_scalable and mu_std):
-            raise NotImplementedError("training-mode plans are built for all_scalable=True, mu_std=True (README config)")
+        if train and not m.all_scalable:
+            raise NotImplementedError("training-mode plans are built for all_scalable=True (README config)")
 
         def supports(j):
             """determine_support (pic.py:264-270): base slice j + the last min(sp, j) entries of the support vectors

@@ -100,6 +100,56 @@ def section_trained_like(get_model, args):
         json.dump(scal, f, indent=1)
 
 
+def section_rem_no_mu_std(get_model, args):
+    """12. (round 4) REM fine-tune step of the ``mu_std=False`` variant (the block sees and refines the scale only,
+    rem_pic.py:194-195,214-220; layers/rem.py:86,100): the reference's own training-mode forward + RateLoss + backward, noise
+    injected as in section 6."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_training_loss3", os.path.join(REF, "training", "loss.py"))
+    loss_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loss_mod)
+    a_ = argparse.Namespace(**{**vars(args), "model": "rem", "mu_std": False})
+    net = quiet(get_model, a_, "cpu").eval()
+    fill(net, 0)
+    x = synth.synth_image(1, 64, 128, seed=0)
+    with torch.no_grad():
+        ck = net.forward_single_quality(x, quality=0.75, training=False)["y_hat"]
+    net.train()
+    net.freeze_all()
+    net.unfreeze_rems()
+    ny = synth.uniform((1, 640, 4, 8), 101) - 0.5
+    nz = synth.uniform((1, 192, 1, 2), 102) - 0.5
+    queue = [nz.transpose(0, 1).reshape(192, 1, -1)] + list(ny.chunk(20, 1))
+    real_uniform = torch.Tensor.uniform_
+
+    def fake_uniform(self, a=0.0, b=1.0):
+        src = queue.pop(0)
+        assert tuple(src.shape) == tuple(self.shape) and (a, b) == (-0.5, 0.5), (src.shape, self.shape, a, b)
+        with torch.no_grad():
+            return self.copy_(src)
+
+    torch.Tensor.uniform_ = fake_uniform
+    try:
+        o = net.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck.clone())
+    finally:
+        torch.Tensor.uniform_ = real_uniform
+    assert not queue
+    crit = loss_mod.RateLoss()(o, x)
+    crit["loss"].backward()
+    rec = {"ck": ck.numpy(), "lik_y": o["likelihoods"]["y"].detach().numpy(), "lik_z": o["likelihoods"]["z"].detach().numpy(),
+           "loss": np.array([crit["loss"].item(), crit["bpp_loss"].item(), crit["bpp_hype"].item()], dtype=np.float64)}
+    names, norms, samples = [], [], []
+    for k, p_ in net.post_latent[0].named_parameters():
+        gflat = p_.grad.detach().reshape(-1)
+        names.append(k)
+        norms.append(gflat.double().norm().item())
+        samples.append(gflat[::53].numpy())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array(norms, dtype=np.float64)
+    rec["grad_samples"] = np.concatenate(samples).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "rem_train_step_no_mu_std.npz"), **rec)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -114,6 +164,8 @@ def main():
                               dimension="middle")
     if os.environ.get("VAMPIC_GOLDEN_ONLY") == "trained_like":      # regenerate this one section (minutes instead of the whole run)
         return section_trained_like(get_model, args)
+    if os.environ.get("VAMPIC_GOLDEN_ONLY") == "rem_no_mu_std":
+        return section_rem_no_mu_std(get_model, args)
     net = quiet(get_model, args, "cpu").eval()
 
     # 1. state_dict manifest
@@ -470,6 +522,7 @@ def main():
         json.dump(scal, f, indent=1)
 
     section_trained_like(get_model, args)              # 11. trained-like weight profile (round 4)
+    section_rem_no_mu_std(get_model, args)             # 12. REM fine-tune step, mu_std = False (round 4)
 
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):

@@ -621,10 +621,11 @@ def eb_likelihood_noise(sd: SD, z: Tensor, noise: Tensor, prefix: str = "entropy
 
 def rem_training_step(sd: SD, x: Tensor, quality: float, checkpoint_ref: Tensor, noise_y: Tensor, noise_z: Tensor, *,
                       check_levels: Sequence[float], div: int = 320, chunk: int = 32, max_support: int = 5,
-                      prog_support: int = 5) -> dict:
+                      prog_support: int = 5, mu_std: bool = True) -> dict:
     """One REM fine-tune step's forward + backward: returns the training-mode likelihoods, RateLoss's bpp and
     dLoss/d(post_latent.<r>.*) by autograd.  Everything outside the REM is frozen (train.py:223-226), so it is
-    evaluated without a graph; masks carry no gradient (hard comparison)."""
+    evaluated without a graph; masks carry no gradient (hard comparison).  ``mu_std`` = False: the block sees and refines
+    the scale only (rem_pic.py:194-195,214-220; layers/rem.py:86,100)."""
     assert quality > check_levels[0]
     ri = rem_index(check_levels, quality)
     pre = f"post_latent.{ri}."
@@ -666,9 +667,13 @@ def rem_training_step(sd: SD, x: Tensor, quality: float, checkpoint_ref: Tensor,
             mu_tot.append(mu + yhat_b[j])
             std_tot.append(sc)
             att = variance_mask(sc, quality)
-            att = torch.cat([att, att], 1)
-        ep = rem_block(sdt, f"{pre}{j}.", ck[j], torch.cat([mu_b[j], std_b[j]], 1), torch.cat([mu, sc], 1), att)
-        mu2, sc2 = ep.chunk(2, 1)
+            if mu_std:
+                att = torch.cat([att, att], 1)
+        if mu_std:
+            ep = rem_block(sdt, f"{pre}{j}.", ck[j], torch.cat([mu_b[j], std_b[j]], 1), torch.cat([mu, sc], 1), att)
+            mu2, sc2 = ep.chunk(2, 1)
+        else:
+            mu2, sc2 = mu, rem_block(sdt, f"{pre}{j}.", ck[j], torch.cat([mu_b[j], std_b[j]], 1), sc, att)
         m = variance_mask(sc2.detach(), quality)
         masks.append(m)
         mu_f.append(mu2)

@@ -244,6 +244,45 @@ def test_rem_train_step_matches_reference_gradients(train_model, use_graph):
     print(f"worst gradient error / norm: {worst:.2e}")
 
 
+def test_rem_train_step_without_mu_std_matches_reference_gradients():
+    """``--model rem`` without ``--mu_std`` (the block refines the scale only; rem_pic.py:194-195,214-220): one fine-tune
+    step against the gradients the REFERENCE computed (tests/golden/rem_train_step_no_mu_std.npz), same bounds as the
+    mu_std step above; dL/dmu stops at the block (mu is not refined)."""
+    import argparse
+    import vampic
+    from conftest import README_ARGS
+    gold = np.load(os.path.join(GOLD, "rem_train_step_no_mu_std.npz"))
+    m = vampic.get_model(argparse.Namespace(model="rem", check_levels=[0.75], mu_std=False, dimension="middle", **README_ARGS), "cpu")
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=0))
+    m = m.cuda().train()
+    m.freeze_all()
+    m.unfreeze_rems()
+    x = synth.synth_image(1, 64, 128, seed=0).cuda()
+    noise = {"y": synth.uniform((1, 640, 4, 8), 101) - 0.5, "z": synth.uniform((1, 192, 1, 2), 102) - 0.5}
+    ck = torch.from_numpy(gold["ck"]).cuda()
+    for use_graph in (False, True):
+        m.use_graph = use_graph
+        m.zero_grad(set_to_none=True)
+        out = m.forward_single_quality(x, quality=2.5, training=True, checkpoint_ref=ck, noise=noise)
+        loss = _rate_loss(out, x)
+        loss.backward()
+        assert _rel(out["likelihoods"]["y"], torch.from_numpy(gold["lik_y"])) <= 5e-4
+        assert abs(float(loss.detach()) - gold["loss"][0]) <= 1e-5 * gold["loss"][0]
+        samples, off, num, den = gold["grad_samples"], 0, 0.0, 0.0
+        params = dict(m.post_latent[0].named_parameters())
+        assert len(params) == len(gold["grad_names"])
+        for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+            g = params[str(name)].grad.reshape(-1).cpu()
+            s = g[::53].numpy()
+            ref = samples[off:off + len(s)]
+            off += len(s)
+            assert abs(float(g.double().norm()) - norm) <= 3e-2 * norm + 1e-12, name
+            num += float(((s - ref).astype(np.float64) ** 2).sum())
+            den += float((ref.astype(np.float64) ** 2).sum())
+        assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+        assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith("post_latent."))
+
+
 def test_rem_finetune_loop_reduces_rate(train_model):
     """The reference's loop shape (training/step.py:56-95): checkpoint under no_grad, training forward, RateLoss,
     backward, clip, Adam.  The rate on a fixed batch must go down, the eval plan must see the new weights, and

@@ -138,6 +138,34 @@ def test_rem_training_step_matches_reference(synth_model_cpu):
     assert off == len(samples)
 
 
+def test_rem_training_step_without_mu_std_matches_reference():
+    """The ``mu_std=False`` REM variant (scale-only refinement, rem_pic.py:194-195,214-220): the oracle's fine-tune step
+    against the reference's own autograd run (oracle/gen_golden.py section 12)."""
+    import argparse
+    import vampic
+    from conftest import README_ARGS
+    gold = np.load(os.path.join(GOLD, "rem_train_step_no_mu_std.npz"))
+    net = vampic.get_model(argparse.Namespace(model="rem", check_levels=[0.75], mu_std=False, dimension="middle", **README_ARGS), "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    x = synth.synth_image(1, 64, 128, seed=0)
+    ny = synth.uniform((1, 640, 4, 8), 101) - 0.5
+    nz = synth.uniform((1, 192, 1, 2), 102) - 0.5
+    o = O.rem_training_step(sd, x, 2.5, torch.from_numpy(gold["ck"]), ny, nz, check_levels=[0.75], mu_std=False)
+    _close(o["likelihoods"]["y"], gold["lik_y"])
+    _close(o["likelihoods"]["z"], gold["lik_z"])
+    assert abs(o["loss"] - gold["loss"][0]) <= 1e-6 * abs(gold["loss"][0])
+    samples, off = gold["grad_samples"], 0
+    assert len(gold["grad_names"]) == len(o["grads"])
+    for name, norm in zip(gold["grad_names"], gold["grad_norms"]):
+        g = o["grads"]["post_latent.0." + str(name)].reshape(-1)
+        s = g[::53].numpy()
+        ref = samples[off:off + len(s)]
+        off += len(s)
+        assert abs(float(g.double().norm()) - norm) <= 1e-5 * norm + 1e-12, name
+        assert np.abs(s - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-10, name
+    assert off == len(samples)
+
+
 def test_flip_audit_separates_boundary_events_from_errors(synth_model_cpu):
     """tests/parity_audit.py (the gate of the GPU end-to-end parity tests) on CPU: two oracle runs whose inputs differ
     by 2e-7 play "reference" and "other back-end" — every differing rounding decision must be classified as a
