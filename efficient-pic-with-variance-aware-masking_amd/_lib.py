@@ -44,7 +44,10 @@ class VamWgrad(C.Structure):
                 ("ld_x", C.c_int), ("ld_dy", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("C", C.c_int), ("N", C.c_int),
                 ("cin_total", C.c_int), ("c_off", C.c_int), ("stride", C.c_int), ("Hx", C.c_int), ("Wx", C.c_int),
-                ("splits", C.c_int), ("workspace", C.c_void_p), ("slot_share", C.c_float), ("pad_", C.c_int32)]
+                ("splits", C.c_int), ("workspace", C.c_void_p), ("slot_share", C.c_float), ("flags", C.c_int32)]
+
+
+WGRAD_X_P3 = 1
 
 
 class VamAux(C.Structure):
@@ -142,6 +145,7 @@ _SIGNATURES = {
     "vam_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vam_conv_wgrad_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vam_conv_wgrad_plan": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vam_conv_wgrad_lds_grid": (C.c_int, [C.c_int, C.c_int]),
     "vam_colsum_workspace": (C.c_size_t, [C.c_long, C.c_int]),
     "vam_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vam_leaky_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),

@@ -389,6 +389,7 @@ __global__ void gauss_train_kernel(const LikArgs a) {
 
 // LDS-tiled kernel for the k3 / k5 layers (wgrad_lds.hip)
 bool wgrad2_eligible(const vam_wgrad& p);
+bool wgrad2_grid(int H, int W);
 int wgrad2_splits(const vam_wgrad& p);
 int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream);
 
@@ -418,6 +419,15 @@ static void wgrad_tile(const vam_wgrad& p, int* tn, int* tc) {
   *tc = c_;
 }
 
+static bool wg_split_on() {             // VAMPIC_WGRAD=f32: the fp32-pipe loop (A/B measurements)
+  static int wg_split = -1;
+  if (wg_split < 0) {
+    const char* e = getenv("VAMPIC_WGRAD");
+    wg_split = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+  }
+  return wg_split != 0;
+}
+
 static int wgrad_splits(const vam_wgrad& p) {
   if (wgrad2_eligible(p)) return wgrad2_splits(p);
   // enough blocks to fill the chip (4 blocks of 8 waves per CU x 256 CUs, twice over), at least 2048 pixels per split
@@ -431,6 +441,8 @@ static int wgrad_splits(const vam_wgrad& p) {
   if (s > 256) s = 256;
   return s < 2 ? 1 : (int)s;
 }
+
+int vam_conv_wgrad_lds_grid(int H, int W) { return wgrad2_grid(H, W) ? 1 : 0; }
 
 int vam_conv_wgrad_plan(const vam_wgrad* p, size_t* workspace_bytes) {
   if (!p || p->B <= 0 || p->H <= 0 || p->W <= 0 || p->C <= 0 || p->N <= 0 || p->kh <= 0) return 1;
@@ -454,6 +466,9 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
     VAM_REQUIRE(p.splits >= 0 && p.splits <= 256 && (p.splits <= 1 || p.workspace), "vam_conv_wgrad_group: problem %d: %d pixel splits need a workspace "
                 "(vam_conv_wgrad_plan)", i, p.splits);
+    VAM_REQUIRE(!(p.flags & VAM_WGRAD_X_P3) || (wg_split_on() && wgrad2_eligible(p)),
+                "vam_conv_wgrad_group: problem %d: a plane (P3) input needs the LDS-tiled kernel (k3 stride 1, C %% 8 == 0, a grid "
+                "vam_conv_wgrad_lds_grid accepts, VAMPIC_WGRAD_LDS / VAMPIC_WGRAD not switched off)", i);
     wgrad_tile(p, &tns[i], &tcs[i]);
     if (p.splits > 1) {
       const long tot = (long)p.N * p.C * p.kh * p.kw + p.N;
@@ -463,12 +478,7 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     const double px = (double)p.B * (p.stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
     if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) small = false;
   }
-  static int wg_split = -1;            // VAMPIC_WGRAD=f32: the fp32-pipe loop (A/B measurements)
-  if (wg_split < 0) {
-    const char* e = getenv("VAMPIC_WGRAD");
-    wg_split = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
-  }
-  const bool use_split = wg_split && small;
+  const bool use_split = wg_split_on() && small;
   WgradArgs wa;
   for (int i = 0; i < n_probs; ++i) wa.p[i] = probs[i];
   ProfScope ps(VAM_FAM_CONV, (hipStream_t)stream, flops, 0);

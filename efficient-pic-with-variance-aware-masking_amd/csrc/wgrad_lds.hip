@@ -64,7 +64,10 @@ __device__ __forceinline__ void w2_split4(const u32x4 v, uint2 (&pl)[3]) {
   pl[2] = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
 }
 
-template <int KW, int STRIDE, int WN, int WC, int W2_KP, int TN = 1, int TC = 1>
+// XP3: the input x arrives as bf16x3 planes ("P3": [pixel][8-channel group][plane][8 bf16], 48 B per group, written by the
+// producing convolution's epilogue, VAM_CONV_OUT_BF3 — the taped activations of the slice stacks): its tile is staged by
+// plain 16-byte copies, no split.  dY is always fp32 (its column sums are the bias gradient).
+template <int KW, int STRIDE, int WN, int WC, int W2_KP, int TN = 1, int TC = 1, int XP3 = 0>
 __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // a wave owns TN x TC blocks of 32 x 32 (1 x 1 for the k3 / k5 layers, whose kw taps already give it kw block products
@@ -138,7 +141,27 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
     x_dst[i] = (unsigned)(((xcc >> 5) * 3 * XPL + lp) * 64 + (xcc & 31) * 2);          // + plane * XPL * 64
   }
 
-  u32x4 ry[NYU], rx[NXU];
+  // X as planes: 16-byte unit u = tid + NT i -> tile pixel u / UPX, unit e = u % UPX of the pixel = (group e / 3, plane e % 3)
+  constexpr int UPX = (W2_CB / 8) * 3;
+  constexpr int NXP = XP3 ? (XP_MAX * UPX + W2_NT - 1) / W2_NT : 1;
+  int x3_r[NXP], x3_j[NXP];
+  unsigned x3_src[NXP], x3_dst[NXP];
+  if constexpr (XP3) {
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const int u = tid + W2_NT * i;
+      const int xp = u / UPX, e = u - xp * UPX;
+      const int gq = e / 3, pl = e - gq * 3;
+      const int r = xp / XW, j = xp - r * XW;
+      x3_r[i] = (xp < R * XW && c0 + 8 * gq < C) ? r : -1;     // (host: C % 8 == 0 for plane tensors)
+      x3_j[i] = j;
+      x3_src[i] = (unsigned)((c0 / 8 + gq) * 48 + pl * 16);
+      const int lp = r * XWL + (STRIDE == 2 ? (j & 1) * XWH + (j >> 1) : j);
+      x3_dst[i] = (unsigned)((((gq >> 2) * 3 + pl) * XPL + lp) * 64 + (gq & 3) * 16);
+    }
+  }
+
+  u32x4 ry[NYU], rx[XP3 ? NXP : NXU];
   auto issue = [&](int q) {
     const int p0 = q << LGKP;
     const int b = p0 / HW;
@@ -151,12 +174,22 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
       ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, (int)(ok ? o : OOB), 0, 0));
     }
     const int ix0 = ox0 * STRIDE - PAD;
+    if constexpr (XP3) {
 #pragma unroll
-    for (int i = 0; i < NXU; ++i) {
-      const int iy = (oy0 + x_r[i]) * STRIDE - PAD + ty, ix = ix0 + x_j[i];
-      const bool ok = xc_ok && x_r[i] >= 0 && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx;
-      const unsigned o = (unsigned)(((b * Hx + iy) * Wx + ix) * pr.ld_x + c0 + xcc) << 2;
-      rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(ok ? o : OOB), 0, 0));
+      for (int i = 0; i < NXP; ++i) {
+        const int iy = (oy0 + x3_r[i]) * STRIDE - PAD + ty, ix = ix0 + x3_j[i];
+        const bool ok = x3_r[i] >= 0 && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx;
+        const unsigned o = (unsigned)(((b * Hx + iy) * Wx + ix) * pr.ld_x) * 48u + x3_src[i];      // ld_x counts groups
+        rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(ok ? o : OOB), 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXU; ++i) {
+        const int iy = (oy0 + x_r[i]) * STRIDE - PAD + ty, ix = ix0 + x_j[i];
+        const bool ok = xc_ok && x_r[i] >= 0 && (unsigned)iy < (unsigned)Hx && (unsigned)ix < (unsigned)Wx;
+        const unsigned o = (unsigned)(((b * Hx + iy) * Wx + ix) * pr.ld_x + c0 + xcc) << 2;
+        rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(ok ? o : OOB), 0, 0));
+      }
     }
   };
   const bool want_db = pr.db != nullptr && ty == 0 && c0 == 0 && pr.c_off == 0;
@@ -175,13 +208,20 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad2_kernel(const Wgrad2Args a
         }
       }
     }
+    if constexpr (XP3) {
 #pragma unroll
-    for (int i = 0; i < NXU; ++i) {
-      if (x_r[i] >= 0) {
-        uint2 pl[3];
-        w2_split4(rx[i], pl);
+      for (int i = 0; i < NXP; ++i)
+        if (tid + W2_NT * i < R * XW * UPX)                       // every unit of the tile is written (zeros where out of range)
+          *reinterpret_cast<u32x4*>(sX + x3_dst[i]) = rx[i];
+    } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sX + x_dst[i] + k * (XPL * 64)) = pl[k];
+      for (int i = 0; i < NXU; ++i) {
+        if (x_r[i] >= 0) {
+          uint2 pl[3];
+          w2_split4(rx[i], pl);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(sX + x_dst[i] + k * (XPL * 64)) = pl[k];
+        }
       }
     }
   };
@@ -309,20 +349,31 @@ static size_t w2_lds_bytes(int kw, int stride, int nbk, int cbk, int kp) {      
 // ---------------------------------------------------------------------------------------------------- host side
 // A problem takes this kernel when its geometry is the one the chunking assumes; everything else (1x1 layers, the small
 // grids of the hyperprior, odd channel counts) stays with wgrad_kernel.
-bool wgrad2_eligible(const vam_wgrad& p) {
+static bool w2_grid_ok(int H, int W) {
+  if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return false;
+  if (((long)H * W) % 64 != 0) return false;
+  if (W < 64 && H % (64 / W) != 0) return false;
+  return true;
+}
+static bool w2_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("VAMPIC_WGRAD_LDS"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on) return false;
+  return on != 0;
+}
+bool wgrad2_grid(int H, int W) { return w2_enabled() && w2_grid_ok(H, W); }
+
+bool wgrad2_eligible(const vam_wgrad& p) {
+  if (!w2_enabled()) return false;
   if (!((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh)) return false;
   if (p.kh == 1 && p.stride == 2) return false;
   const int stride = p.stride == 2 ? 2 : 1;
-  if (!(p.W == 16 || p.W == 32 || (p.W >= 64 && p.W % 64 == 0))) return false;
-  if (((long)p.H * p.W) % 64 != 0) return false;
-  if (p.W < 64 && p.H % (64 / p.W) != 0) return false;
-  if (p.N % 4 || p.C % 4 || p.ld_x % 4 || p.ld_dy % 4) return false;
+  if (!w2_grid_ok(p.H, p.W)) return false;
+  const bool xp3 = (p.flags & VAM_WGRAD_X_P3) != 0;
+  if (xp3 && !(p.kh == 3 && stride == 1 && p.C % 8 == 0)) return false;
+  if (p.N % 4 || p.C % 4 || (!xp3 && p.ld_x % 4) || p.ld_dy % 4) return false;
   if ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15) return false;
   const double px = (double)p.B * (stride == 2 ? (double)p.Hx * p.Wx : (double)p.H * p.W);
-  if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * 4.0 >= 2147483648.0) return false;
+  if ((double)p.B * p.H * p.W * p.ld_dy * 4.0 >= 2147483648.0 || px * p.ld_x * (xp3 ? 48.0 : 4.0) >= 2147483648.0) return false;
   if (p.C < 16 || p.N < 32) return false;
   return true;
 }
@@ -360,8 +411,9 @@ W2Tile wgrad2_tile(const vam_wgrad& p) {
   //   N a multiple of 96 with few n tiles (96 -> 96 of the residual units): 3 x 2 waves, 96 x 64 tile;
   //   k5 stride 2 below 65536 output pixels: 4 x 2 waves with 64-pixel chunks (the 2 SEGW + 5 input pixels per row make
   //     32-pixel chunks pay two staging rounds per MFMA block there: 136 vs 119 TF/s).
-  const int fkp = w2_force_kp();
-  if (fn > 0)
+  const bool xp3 = (p.flags & VAM_WGRAD_X_P3) != 0;             // plane inputs: the automatic choice only (three instantiations)
+  const int fkp = xp3 ? 0 : w2_force_kp();
+  if (fn > 0 && !xp3)
     for (const W2Tile& t : w2_tiles_k35)
       if (t.wn == fn && t.wc == fc) return W2Tile{t.wn, t.wc, 1, 1, fkp ? fkp : (p.stride == 2 ? 32 : 64)};
   const long P = (long)p.B * p.H * p.W;
@@ -411,15 +463,15 @@ int wgrad2_splits(const vam_wgrad& p) {
   return (int)best_s;
 }
 
-template <int KW, int STRIDE, int WN, int WC, int KP, int TN = 1, int TC = 1>
+template <int KW, int STRIDE, int WN, int WC, int KP, int TN = 1, int TC = 1, int XP3 = 0>
 static int w2_launch(const Wgrad2Args& a, int max_blocks, int n_sub, hipStream_t s) {
   static bool attr = false;
   const size_t lds = w2_lds_bytes(KW, STRIDE, WN * TN, WC * TC, KP);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC, XP3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC>), dim3(max_blocks, n_sub), dim3(64 * WN * WC), lds, s, a);
+  hipLaunchKernelGGL((wgrad2_kernel<KW, STRIDE, WN, WC, KP, TN, TC, XP3>), dim3(max_blocks, n_sub), dim3(64 * WN * WC), lds, s, a);
   return check_launch("wgrad2_kernel");
 }
 
@@ -445,7 +497,8 @@ int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
     for (int i = i0; i < n; ++i) {
       if (done[i]) continue;
       const W2Tile ti = wgrad2_tile(probs[i]);
-      if (ti.wn != t.wn || ti.wc != t.wc || ti.kp != t.kp || ti.tn != t.tn || ti.tc != t.tc) continue;
+      if (ti.wn != t.wn || ti.wc != t.wc || ti.kp != t.kp || ti.tn != t.tn || ti.tc != t.tc ||
+          ((probs[i].flags ^ probs[i0].flags) & VAM_WGRAD_X_P3)) continue;
       done[i] = true;
       const vam_wgrad& p = probs[i];
       a.p[n_sub++] = p;
@@ -454,7 +507,11 @@ int wgrad2_launch_class(const vam_wgrad* probs, int n, hipStream_t stream) {
       max_blocks = nb > max_blocks ? nb : max_blocks;
     }
     int rc;
-    if (kw == 1) {
+    if (a.p[0].flags & VAM_WGRAD_X_P3) {                        // k3 stride 1, automatic tile, 32-pixel chunks
+      if (t.wn == 2 && t.wc == 2) rc = w2_launch<3, 1, 2, 2, 32, 1, 1, 1>(a, max_blocks, n_sub, stream);
+      else if (t.wn == 4 && t.wc == 1) rc = w2_launch<3, 1, 4, 1, 32, 1, 1, 1>(a, max_blocks, n_sub, stream);
+      else rc = w2_launch<3, 1, 3, 2, 32, 1, 1, 1>(a, max_blocks, n_sub, stream);
+    } else if (kw == 1) {
       if (t.tn == 2 && t.tc == 1) rc = w2_launch<1, 1, 3, 2, 32, 2, 1>(a, max_blocks, n_sub, stream);
       else if (t.tn == 1 && t.tc == 2) rc = w2_launch<1, 1, 3, 2, 32, 1, 2>(a, max_blocks, n_sub, stream);
       else rc = w2_launch<1, 1, 2, 2, 32, 2, 2>(a, max_blocks, n_sub, stream);

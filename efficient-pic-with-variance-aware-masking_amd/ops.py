@@ -590,6 +590,9 @@ def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optio
         p.x, p.dy, p.dw = v.ptr, dy.ptr, dw.data_ptr()
         p.db = db.data_ptr() if (db is not None and off == 0) else None
         p.ld_x, p.ld_dy, p.B, p.H, p.W, p.kh, p.kw, p.C, p.N = v.ld, dy.ld, dy.B, dy.H, dy.W, kh, kw, v.C, n
+        if isinstance(v, View3):          # taped activation stored as bf16x3 planes: the LDS-tiled kernel copies instead of splitting
+            assert kh == 3 and stride == 1 and wgrad_reads_planes(dy.H, dy.W), "plane inputs: k3 stride-1 layers on an LDS-kernel grid"
+            p.flags = L.WGRAD_X_P3
         p.cin_total, p.c_off = cin_total, off
         p.stride, p.Hx, p.Wx = stride, v.H, v.W
         p._dev = dy.buf.device
@@ -598,6 +601,14 @@ def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optio
         off += v.C
     wgrad_plan(out)                       # alone; a grouped launch re-plans with each problem's share of the group
     return out
+
+
+def wgrad_reads_planes(H: int, W: int) -> bool:
+    """True when the weight gradient of a k3 stride-1 layer on an H x W grid takes the LDS-tiled kernel, which can read its
+    input as bf16x3 planes (``View3``): the taped activations of the slice stacks are then written as planes only."""
+    if os.environ.get("VAMPIC_TRAIN_P3", "1") == "0":        # A/B arm: fp32 activations on the tape everywhere
+        return False
+    return split_mode() and bool(L.load().vam_conv_wgrad_lds_grid(int(H), int(W)))
 
 
 def wgrad_plan(problems: Sequence[L.VamWgrad]):

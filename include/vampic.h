@@ -351,8 +351,13 @@ typedef struct vam_wgrad {
   float* workspace;   /* pixels are cut into `splits` ranges whose partial tiles go to this caller-owned buffer and   */
                       /* are added in range order by a second launch (layers with few weight tiles and many pixels)  */
   float slot_share;   /* planning hint (vam_conv_wgrad_plan only): the fraction of the chip this problem can count on  */
-  int32_t pad_;       /* when it shares a grouped launch with others (its share of the group's FLOPs); 0 = alone       */
+                      /* when it shares a grouped launch with others (its share of the group's FLOPs); 0 = alone       */
+  int32_t flags;      /* VAM_WGRAD_X_P3: x is a bf16x3 plane tensor (VAM_CONV_OUT_BF3 layout; ld_x counts 8-channel     */
+                      /* groups per pixel) — k3 stride-1 problems on grids vam_conv_wgrad_lds_grid() accepts only      */
 } vam_wgrad;
+#define VAM_WGRAD_X_P3 1
+/* 1 when weight gradients on an H x W output grid take the LDS-tiled kernel (which alone reads plane tensors). */
+int vam_conv_wgrad_lds_grid(int H, int W);
 /* Suggested number of pixel splits for a problem (>= 1) and the workspace it needs (0 bytes when 1). */
 int vam_conv_wgrad_plan(const vam_wgrad* problem, size_t* workspace_bytes);
 int vam_conv_wgrad_group(const vam_wgrad* problems, int n_problems, void* stream);

@@ -1,0 +1,12 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 400 python -m pytest tests/test_gpu_wgrad_lds.py tests/test_gpu_first_train.py tests/test_gpu_train_gs.py -q -k "wgrad or plane or slice_stack or first_train_step or refine_gs_lrp or reproducible or mixed" > gpurun_out/r4_t10.log 2>&1; tail -6 gpurun_out/r4_t10.log
+for i in 1 2; do
+  timeout -k 10 300 python scripts/bench_train.py --steps 5 --warmup 2 > gpurun_out/r4_p3on_$i.log 2>&1
+  VAMPIC_TRAIN_P3=0 timeout -k 10 300 python scripts/bench_train.py --steps 5 --warmup 2 > gpurun_out/r4_p3off_$i.log 2>&1
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r4_p3o*_*.log')):
+    d=json.loads([l for l in open(f) if l.startswith('{')][-1]); print(f, d['ms_per_step'], d['phase_ms'], d['config']['loss'])
+PY

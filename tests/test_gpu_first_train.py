@@ -64,6 +64,15 @@ def test_slice_stack_backward_with_segmented_input():
                  [(2, 320, 4, 8), (2, 64, 4, 8), (2, 32, 4, 8)], None, 31)
 
 
+def test_slice_stack_backward_on_the_latent_grid_of_the_full_size_step():
+    """The same stack on a 16 x 16 grid (what a 256 x 256 image gives): weight gradients take the LDS-tiled kernel and the
+    intermediate activations travel as bf16x3 planes (forward convolution and weight gradient both read them as planes)."""
+    from vampic.models import _param_stack
+    assert ops.wgrad_reads_planes(16, 16)
+    _stack_check(_param_stack(320 + 64 + 32, 320), lambda sd, x: O.cc_stack(sd, "m.", x),
+                 [(2, 320, 16, 16), (2, 64, 16, 16), (2, 32, 16, 16)], None, 33)
+
+
 def test_hyper_analysis_backward_stride2():
     """h_a (builder.py:72-82): conv3x3 stride 2 — data gradient by zero insertion + the stride-1 data-gradient problem,
     weight gradient by the stride-2 wgrad."""

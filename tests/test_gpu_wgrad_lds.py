@@ -85,3 +85,33 @@ def test_mixed_group_routes_each_problem_to_its_kernel():
     torch.cuda.synchronize()
     for dw, ref, db, refb, _, _ in out:
         assert _rel(dw, ref) <= 2e-5 and _rel(db, refb) <= 2e-5
+
+
+@pytest.mark.parametrize("segs,n,hw,B", [((224,), 176, (16, 16), 2), ((64,), 64, (32, 32), 1), ((24,), 64, (16, 16), 2), ((96,), 96, (16, 16), 2)])
+def test_plane_input_gives_the_same_bits_as_fp32_input(segs, n, hw, B):
+    """X handed over as bf16x3 planes (the taped activations of the slice stacks, written by the producing launch's
+    epilogue): the staged tile holds the same three bf16 terms as the in-kernel split of the fp32 tensor, so the weight
+    gradient is bit-identical."""
+    from vampic import engine as E
+    H, W = hw
+    c = segs[0]
+    x = synth.normal((B, c, H, W), 3)
+    dy = synth.normal((B, n, H, W), 9)
+    xv, dyv = ops.from_nchw(x.cuda()), ops.from_nchw(dy.cuda())
+    x3 = ops.new_view3(B, H, W, c)
+    ops.conv_group([ops.conv_problem(E._identity_pack(c, "cuda"), [xv], x3)])       # exact: 1.0 * x, then the epilogue's split
+    assert torch.equal(x3.to_float().cpu(), xv.buf.cpu())
+    assert ops.wgrad_reads_planes(H, W)
+    res = []
+    for inp in (xv, x3):
+        dw = torch.full((n, c, 3, 3), float("nan"), device="cuda")
+        db = torch.full((n,), float("nan"), device="cuda")
+        probs = ops.wgrad_problems([inp], dyv, dw, db)
+        assert bool(probs[0].flags & L.WGRAD_X_P3) == (inp is x3)
+        ops.wgrad_group(probs)
+        torch.cuda.synchronize()
+        res.append((dw, db))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    w = synth.normal((n, c, 3, 3), 1, 0.1).requires_grad_(True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    assert _rel(res[1][0], w.grad) <= 2e-5
