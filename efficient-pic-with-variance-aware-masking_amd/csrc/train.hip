@@ -463,7 +463,8 @@ int vam_conv_wgrad_group(const vam_wgrad* probs, int n_probs, void* stream) {
     VAM_REQUIRE((p.kh == 1 || p.kh == 3 || p.kh == 5) && p.kw == p.kh, "vam_conv_wgrad_group: square odd kernels (pad k/2)");
     VAM_REQUIRE(p.stride == 0 || p.stride == 1 || (p.stride == 2 && p.kh >= 3 && p.Hx == 2 * p.H && p.Wx == 2 * p.W),
                 "vam_conv_wgrad_group: problem %d: stride %d (1, or 2 with k3 / k5 and x of extent 2H x 2W)", i, p.stride);
-    VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x >= p.C && p.ld_dy >= p.N, "vam_conv_wgrad_group: problem %d: channel window", i);
+    VAM_REQUIRE(p.c_off >= 0 && p.c_off + p.C <= p.cin_total && p.ld_x * ((p.flags & VAM_WGRAD_X_P3) ? 8 : 1) >= p.C && p.ld_dy >= p.N,
+                "vam_conv_wgrad_group: problem %d: channel window", i);
     VAM_REQUIRE(p.splits >= 0 && p.splits <= 256 && (p.splits <= 1 || p.workspace), "vam_conv_wgrad_group: problem %d: %d pixel splits need a workspace "
                 "(vam_conv_wgrad_plan)", i, p.splits);
     VAM_REQUIRE(!(p.flags & VAM_WGRAD_X_P3) || (wg_split_on() && wgrad2_eligible(p)),

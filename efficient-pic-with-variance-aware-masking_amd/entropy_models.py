@@ -21,7 +21,6 @@ from . import bitstream as bs
 from . import ops
 from .layers import _LowerBound, _no_autograd
 
-_NOT_BUILT = "training-mode paths (noise, autograd, aux loss) need the backward kernels (SURVEY K14); not built yet"
 
 
 class _EbAuxLoss(torch.autograd.Function):

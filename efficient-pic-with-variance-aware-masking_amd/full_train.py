@@ -214,10 +214,10 @@ class FullTrainPlan:
 
     def __init__(self, m, B: int, H: int, W: int, mode: str, base_only: bool, device, trainable_ids: Optional[set] = None):
         assert mode in ("multi", "single") and not (mode == "multi" and base_only)
-        if not (m.multiple_encoder and m.multiple_decoder and m.multiple_hyperprior and m.all_scalable and m.delta_encode
-                and m.total_mu_rep):
-            raise NotImplementedError("the first-stage training plan is built for the README configuration (dual encoder / "
-                                      "decoder / hyperprior, all_scalable, delta_encode, total_mu_rep)")
+        if not (m.all_scalable and m.delta_encode and m.total_mu_rep):
+            raise NotImplementedError("the first-stage training plan is built for all_scalable, delta_encode, total_mu_rep (the "
+                                      "README values); the encoder / decoder / hyperprior may each be single or dual")
+        me, md, mh = bool(m.multiple_encoder), bool(m.multiple_decoder), bool(m.multiple_hyperprior)
         self.m, self.B, self.H, self.W, self.mode, self.base_only = m, B, H, W, mode, base_only
         self.device = torch.device(device)
         self.pr = 10.0
@@ -237,15 +237,19 @@ class FullTrainPlan:
         dec_prog = not base_only
 
         # ------------------------------------------------------------------ modules on the path and their packs
-        self.enc = [m.g_a[0], m.g_a[1]]
-        self.hs_m = [m.h_mean_s[k] for k in range(nh)]
-        self.hs_s = [m.h_scale_s[k] for k in range(nh)]
+        # single encoder: one g_a with M outputs (pic.py:306-307); single hyperprior: one synthesis pair with M outputs,
+        # whatever the quality (pic.py:285-288); single decoder: ONE g_s reconstructs both levels (pic.py:372,462-466)
+        self.enc = [m.g_a[0], m.g_a[1]] if me else [m.g_a]
+        self.hs_m = [m.h_mean_s[k] for k in range(nh)] if mh else [m.h_mean_s]
+        self.hs_s = [m.h_scale_s[k] for k in range(nh)] if mh else [m.h_scale_s]
+        nhc = nh if mh else 2                                    # d-channel halves the hyper-synthesis tensors hold
+        gs_base, gs_prog = (m.g_s[0], m.g_s[1]) if md else (m.g_s, m.g_s)
         base_st = [m.cc_mean_transforms[i] for i in range(ns)] + [m.cc_scale_transforms[i] for i in range(ns)] + \
                   [m.lrp_transforms[i] for i in range(ns)]
         prog_st = [] if base_only else ([m.cc_mean_transforms_prog[j] for j in range(ns)] +
                                         [m.cc_scale_transforms_prog[j] for j in range(ns)] +
                                         [m.lrp_transforms_prog[j] for j in range(ns)])
-        self.decs = ([m.g_s[0]] if dec_base else []) + ([m.g_s[1]] if dec_prog else [])
+        self.decs = ([gs_base] if dec_base else []) + ([gs_prog] if (dec_prog and not (dec_base and gs_prog is gs_base)) else [])
         mods = self.enc + [m.h_a] + self.hs_m + self.hs_s + base_st + prog_st + self.decs
         self.pk: Dict[int, G.TransformPacks] = {id(mod): G.TransformPacks(mod) for mod in mods}
         pk = lambda mod: self.pk[id(mod)]
@@ -261,7 +265,7 @@ class FullTrainPlan:
         x_s2d = P.buf(B, H // 2, W // 2, 16)
         P.call(lambda: L.check(L.load().vam_s2d_input(self.x_in.data_ptr(), x_s2d.ptr, B, H, W, ops.stream_ptr()), "vam_s2d_input"))
         y = self.y = P.buf(B, h, w, 2 * d)
-        self.t_ga = [lower_g_a_train(P, e, x_s2d, y.window(k * d, d), pk(e)) for k, e in enumerate(self.enc)]
+        self.t_ga = [lower_g_a_train(P, e, x_s2d, y.window(k * d, d) if me else y, pk(e)) for k, e in enumerate(self.enc)]
 
         z = self.z = P.buf(B, h // 4, w // 4, m.N)
         self.t_ha = lower_stacks_train(P, [m.h_a], [[y]], [z], [pk(m.h_a)])
@@ -277,9 +281,11 @@ class FullTrainPlan:
             torch.cat([getattr(eb, n).detach().reshape(-1) for n in self.eb_names], out=self.eb_params)
         P.call(eb_pack, "entropy-bottleneck parameter block")
         P.call(lambda: ops.eb_forward(z, self.eb_params, self.z_hat, self.z_lik, None, noise=self.noise_z), "eb forward (noise)")
-        means_h, scales_h = P.buf(B, h, w, nh * d), P.buf(B, h, w, nh * d)
-        self.t_hs = lower_stacks_train(P, self.hs_m + self.hs_s, [[self.z_hat]] * (2 * nh),
-                                       [means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)],
+        means_h, scales_h = P.buf(B, h, w, nhc * d), P.buf(B, h, w, nhc * d)
+        nst = len(self.hs_m)
+        self.t_hs = lower_stacks_train(P, self.hs_m + self.hs_s, [[self.z_hat]] * (2 * nst),
+                                       ([means_h.window(k * d, d) for k in range(nh)] + [scales_h.window(k * d, d) for k in range(nh)])
+                                       if mh else [means_h, scales_h],
                                        [pk(s_) for s_ in self.hs_m + self.hs_s])
         mh0, sh0 = means_h.window(0, d), scales_h.window(0, d)
 
@@ -309,7 +315,7 @@ class FullTrainPlan:
                 P.call(lambda k=k, i=i, t_l=t_l: ops.ew(L.EW_HTANH_FWD, [t_l[k]["out"], sl(yq, i), zero32], [sl(yb, i)]), "lrp tail")
             self.t_base.append(dict(idx=idx, sup=sup, ms=t_ms, lrp=t_l))
         if dec_base:
-            self.t_gs0 = G.lower_g_s_train(P, m.g_s[0], yb, self.x_hat[0], pk(m.g_s[0]), clamp=clamp)
+            self.t_gs0 = G.lower_g_s_train(P, gs_base, yb, self.x_hat[0], pk(gs_base), clamp=clamp)
 
         # ---- progressive slices (pic.py:396-457)
         if dec_prog:
@@ -339,21 +345,23 @@ class FullTrainPlan:
                                               [pk(s) for s in lst])
             for j in range(ns):
                 P.call(lambda j=j: ops.ew(L.EW_HTANH_FWD, [self.t_lrp_p[j]["out"], sl(rq, j), sl(yb, j)], [sl(yp, j)]), "lrp tail (prog)")
-            self.t_gs1 = G.lower_g_s_train(P, m.g_s[1], yp, self.x_hat[n_rec - 1], pk(m.g_s[1]), clamp=clamp)
+            self.t_gs1 = G.lower_g_s_train(P, gs_prog, yp, self.x_hat[n_rec - 1], pk(gs_prog), clamp=clamp)
 
         # ------------------------------------------------------------------ parameters and the flat gradient buffer
         # order = the order in which the backward FINISHES them (so that buckets complete front to back)
         order: List[nn.Parameter] = []
         add = lambda mod: order.extend(mod.parameters())
+        shared_dec = dec_prog and dec_base and gs_prog is gs_base     # one decoder, two passes: final after the second
         if dec_prog:
-            add(m.g_s[1])
+            if not shared_dec:
+                add(gs_prog)
             for j in range(ns):
                 add(m.lrp_transforms_prog[j])
             for j in range(ns - 1, -1, -1):
                 add(m.cc_mean_transforms_prog[j])
                 add(m.cc_scale_transforms_prog[j])
         if dec_base:
-            add(m.g_s[0])
+            add(gs_base)
         for idx in reversed(self.base_groups):
             for i in idx:
                 add(m.lrp_transforms[i])
@@ -366,8 +374,8 @@ class FullTrainPlan:
         eb_ps = [getattr(eb, n) for n in self.eb_names]
         order.extend(eb_ps)
         add(m.h_a)
-        add(m.g_a[0])
-        add(m.g_a[1])
+        for e in self.enc:
+            add(e)
         self.params = order
         self.trainable_ids = trainable_ids
         offs, tot = [], 0
@@ -388,7 +396,7 @@ class FullTrainPlan:
         bw.keep.append(self.g_xhat)
         D_y = bw.buf(B, h, w, 2 * d, zero=True)
         D_yb = bw.buf(B, h, w, d, zero=True)
-        D_mh, D_sh = bw.buf(B, h, w, nh * d, zero=True), bw.buf(B, h, w, nh * d, zero=True)
+        D_mh, D_sh = bw.buf(B, h, w, nhc * d, zero=True), bw.buf(B, h, w, nhc * d, zero=True)
         accs = [D_y, D_yb, D_mh, D_sh]
         if dec_prog:
             D_mutot, D_stdp = bw.buf(B, h, w, d, zero=True), bw.buf(B, h, w, d, zero=True)
@@ -416,8 +424,9 @@ class FullTrainPlan:
 
         if dec_prog:
             g1 = self.g_xhat[n_rec - 1]
-            d_yp = G.lower_g_s_backward(bw, self.t_gs1, self.x_hat[n_rec - 1], g1, pk(m.g_s[1]), grads, need_input_grad=True, clamp=clamp)
-            done(m.g_s[1])
+            d_yp = G.lower_g_s_backward(bw, self.t_gs1, self.x_hat[n_rec - 1], g1, pk(gs_prog), grads, need_input_grad=True, clamp=clamp)
+            if not shared_dec:
+                done(gs_prog)
             acc(D_yb, d_yp)                                                           # merge: y_hat = r_hat + y_hat_base (pic.py:451)
             dzl = []
             for j in range(ns):
@@ -457,9 +466,27 @@ class FullTrainPlan:
                 scatter(dxm, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []))
                 scatter(dxs_, [(D_sh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_stdp, j - s_, s_), C * s_)] if s_ else []))
         if dec_base:
-            d_yb0 = G.lower_g_s_backward(bw, self.t_gs0, self.x_hat[0], self.g_xhat[0], pk(m.g_s[0]), grads, need_input_grad=True,
+            g0 = grads
+            if shared_dec:
+                # the same parameters took part in the progressive pass above: this pass writes its gradients into a scratch
+                # copy of the decoder's range of the flat buffer, and ONE element-wise launch adds the two
+                ps = list(gs_base.parameters())
+                pos = {id(p_): i for i, p_ in enumerate(order)}
+                lo_ = offs[pos[id(ps[0])]]
+                hi_ = offs[pos[id(ps[-1])]] + (ps[-1].numel() + 3) // 4 * 4
+                tmp = torch.zeros(hi_ - lo_, **f32)
+                bw.keep.append(tmp)
+                g0 = dict(grads)
+                for p_ in ps:
+                    o_ = offs[pos[id(p_)]] - lo_
+                    g0[id(p_)] = tmp[o_:o_ + p_.numel()].view(p_.shape)
+                main = self.flat[lo_:hi_]
+            d_yb0 = G.lower_g_s_backward(bw, self.t_gs0, self.x_hat[0], self.g_xhat[0], pk(gs_base), g0, need_input_grad=True,
                                          clamp=clamp)
-            done(m.g_s[0])
+            if shared_dec:
+                bw.call(lambda: ops.ew(L.EW_AXPY, [ops.flat_view(main), ops.flat_view(tmp)], [ops.flat_view(main)], coef=1.0),
+                        "single decoder: sum of the two passes' gradients")
+            done(gs_base)
             acc(D_yb, d_yb0)
         # ---- base slices, last group first
         dmu_b, dsg_b = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
@@ -495,8 +522,8 @@ class FullTrainPlan:
                 scatter(dxs[len(idx) + k], [(D_sh.window(0, d), d)] + ([(sl(D_yb, 0, n_sup // C), n_sup)] if n_sup else []))
         # ---- hyperprior
         hs = self.hs_m + self.hs_s
-        dxs = lower_stacks_backward(bw, self.t_hs, [D_mh.window(k * d, d) for k in range(nh)] + [D_sh.window(k * d, d) for k in range(nh)],
-                                    [pk(s) for s in hs], grads)
+        dxs = lower_stacks_backward(bw, self.t_hs, ([D_mh.window(k * d, d) for k in range(nh)] + [D_sh.window(k * d, d) for k in range(nh)])
+                                    if mh else [D_mh, D_sh], [pk(s) for s in hs], grads)
         for s in hs:
             done(s)
         D_z = bw.buf(B, h // 4, w // 4, m.N)
@@ -517,7 +544,7 @@ class FullTrainPlan:
         done(m.h_a)
         acc(D_y, dxy)
         for k, e in enumerate(self.enc):
-            lower_g_a_backward(bw, self.t_ga[k], D_y.window(k * d, d), pk(e), grads)
+            lower_g_a_backward(bw, self.t_ga[k], D_y.window(k * d, d) if me else D_y, pk(e), grads)
             done(e)
         # ------------------------------------------------------------------ buckets
         from .sharding import bucket_partition

@@ -26,8 +26,9 @@ from . import ops
 def _no_autograd(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "libvampic implements the forward (inference/eval) pass; backward kernels are not built yet — "
-            "call under torch.no_grad()")
+            "this module-level call runs the evaluation kernels only: gradients flow through the model-level training plans "
+            "(model(x, quality=[0, q], training=True), forward_single_quality(..., training=True)) and the training-mode "
+            "entropy models — call it under torch.no_grad()")
 
 
 class _Packable(nn.Module):

@@ -22,7 +22,7 @@ from . import _lib as L
 from . import engine as E
 from . import layers as Ly
 from . import ops
-from .entropy_models import EntropyBottleneck, GaussianConditional, get_scale_table, _NOT_BUILT
+from .entropy_models import EntropyBottleneck, GaussianConditional, get_scale_table
 
 
 # ----------------------------------------------------------------------------- builders

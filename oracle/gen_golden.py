@@ -150,6 +150,67 @@ def section_rem_no_mu_std(get_model, args):
     np.savez_compressed(os.path.join(GOLD, "rem_train_step_no_mu_std.npz"), **rec)
 
 
+TRAIN_VARIANTS = ("single_encoder", "single_decoder", "single_hyperprior", "all_single")
+
+
+def section_first_train_variants(get_model, args):
+    """13. (round 4) first-stage training step (section 10's procedure: ``forward(x, [0, 10], training=True)``,
+    ScalableRateDistortionLoss, backward of every parameter, injected noise) for the constructor variants with a single
+    encoder / decoder / hyperprior (models/__init__.py:11-55; pic.py:285-288,306-311,372,462-466): losses, likelihoods,
+    strided reconstructions and every 997th element of every gradient."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_training_loss4", os.path.join(REF, "training", "loss.py"))
+    loss_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loss_mod)
+    xt = synth.synth_image(2, 64, 64, seed=5)
+    ny = synth.uniform((2, 640, 4, 4), 201) - 0.5
+    nz = synth.uniform((2, 192, 1, 1), 202) - 0.5
+    rec = {}
+    for name in TRAIN_VARIANTS:
+        a_ = argparse.Namespace(**{**vars(args), "model": "pic", **CONFIG_VARIANTS[name]})
+        net = quiet(get_model, a_, "cpu").train()
+        fill(net, 0)
+        for p_ in net.parameters():
+            p_.requires_grad = True
+        queue = [nz.transpose(0, 1).reshape(192, 1, -1)] + list(ny.chunk(20, 1))
+        real = torch.Tensor.uniform_
+
+        def fake(self, a=0.0, b=1.0):
+            src = queue.pop(0)
+            assert tuple(src.shape) == tuple(self.shape) and (a, b) == (-0.5, 0.5), (src.shape, self.shape, a, b)
+            with torch.no_grad():
+                return self.copy_(src)
+        torch.Tensor.uniform_ = fake
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                o = net(xt, quality=[0, 10], training=True)
+                crit = loss_mod.ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device="cpu")(o, xt)
+        finally:
+            torch.Tensor.uniform_ = real
+        assert not queue
+        crit["loss"].backward()
+        rec[name + "_loss"] = np.array([crit[k].mean().item() for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype")], dtype=np.float64)
+        rec[name + "_mse"] = crit["mse_loss"].detach().double().numpy()
+        rec[name + "_x_hat"] = o["x_hat"].detach()[:, :, :, ::4, ::4].numpy()
+        rec[name + "_lik_y"] = o["likelihoods"]["y"].detach().numpy()
+        rec[name + "_lik_y_prog"] = o["likelihoods"]["y_prog"].detach().numpy()
+        rec[name + "_lik_z"] = o["likelihoods"]["z"].detach().numpy()
+        rec[name + "_y_hat_base"] = o["y_hat"][0].detach().numpy()
+        names, norms, samples = [], [], []
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None, (name, k)
+            gflat = p_.grad.detach().reshape(-1)
+            names.append(k)
+            norms.append(gflat.double().norm().item())
+            samples.append(gflat[::997].numpy())
+        rec[name + "_grad_names"] = np.array(names)
+        rec[name + "_grad_norms"] = np.array(norms, dtype=np.float64)
+        rec[name + "_grad_samples"] = np.concatenate(samples).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "first_train_variants.npz"), **rec)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -166,6 +227,8 @@ def main():
         return section_trained_like(get_model, args)
     if os.environ.get("VAMPIC_GOLDEN_ONLY") == "rem_no_mu_std":
         return section_rem_no_mu_std(get_model, args)
+    if os.environ.get("VAMPIC_GOLDEN_ONLY") == "first_train_variants":
+        return section_first_train_variants(get_model, args)
     net = quiet(get_model, args, "cpu").eval()
 
     # 1. state_dict manifest
@@ -523,6 +586,7 @@ def main():
 
     section_trained_like(get_model, args)              # 11. trained-like weight profile (round 4)
     section_rem_no_mu_std(get_model, args)             # 12. REM fine-tune step, mu_std = False (round 4)
+    section_first_train_variants(get_model, args)      # 13. first-stage training step, single encoder / decoder / hyperprior (round 4)
 
     print("golden vectors written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):

@@ -752,9 +752,11 @@ def _ste_forced(x: Tensor, q: Optional[Tensor]) -> Tensor:
 
 def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, *,
                      single: bool = False, div: int = 320, chunk: int = 32, max_support: int = 5,
-                     prog_support: int = 5, force: Optional[dict] = None) -> dict:
-    """Training-mode forward, README flags (dual encoder / decoder / hyperprior, delta_encode, total_mu_rep,
-    all_scalable).  ``single`` = False: ``forward(x, quality=[0, q])`` — both decoders, no clamp, likelihoods
+                     prog_support: int = 5, force: Optional[dict] = None, multiple_encoder: bool = True,
+                     multiple_decoder: bool = True, multiple_hyperprior: bool = True) -> dict:
+    """Training-mode forward with delta_encode, total_mu_rep, all_scalable as in the README configuration; the encoder /
+    decoder / hyperprior may each be single (pic.py:285-288,306-311,372,462-466: one g_a with M outputs, one g_s used for
+    both reconstructions, one synthesis pair with M outputs).  ``single`` = False: ``forward(x, quality=[0, q])`` — both decoders, no clamp, likelihoods
     {"y": base, "y_prog": [1, B, 640] = base AND progressive (pic.py:389-390,471-472), "z"}.  ``single`` = True:
     ``forward_single_quality(x, q)`` — the decoder in use, ``clamp_(0, 1)``, likelihoods {"y", "z"}.  ``noise_y`` [B,640,h,w]
     / ``noise_z`` [B,192,h/4,w/4]: the U(-.5,.5) draws of quantize("noise") (entropy_models.py:132-138).
@@ -767,12 +769,14 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
     assert (single and len(qs) == 1) or (not single and len(qs) == 2 and qs[0] == 0)
     q = qs[-1]
     base_only = single and q == 0
-    y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1)                       # pic.py:309-311
+    y = torch.cat([g_a(sd, "g_a.0.", x), g_a(sd, "g_a.1.", x)], 1) if multiple_encoder else g_a(sd, "g_a.", x)   # pic.py:306-311
     z = h_a(sd, y)                                                                       # :280
     z_lik = eb_likelihood_noise_bounded(sd, z, noise_z)
     med = sd["entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
     z_hat = _ste_forced(z - med, force.get("z_sym")) + med                               # :282-284
-    if base_only:                                                                        # :285-288 (quality == 0)
+    if not multiple_hyperprior:                                                          # :285-288: one pair, M channels
+        means_h, scales_h = h_s(sd, "h_mean_s.", z_hat), h_s(sd, "h_scale_s.", z_hat)
+    elif base_only:                                                                      # :285-288 (quality == 0)
         means_h, scales_h = h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_scale_s.0.", z_hat)
     else:
         means_h = torch.cat([h_s(sd, "h_mean_s.0.", z_hat), h_s(sd, "h_mean_s.1.", z_hat)], 1)
@@ -798,7 +802,7 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
     lik_base = torch.cat(lik_b, 1)
     x_hats = []
     if not single or base_only:
-        xb = g_s(sd, "g_s.0.", y_base)                                                   # :372
+        xb = g_s(sd, "g_s.0." if multiple_decoder else "g_s.", y_base)                   # :372
         x_hats.append(xb.clamp(0, 1) if single else xb)
     if base_only:
         out.update({"x_hat": x_hats[0], "likelihoods": {"y": lik_base, "z": z_lik}, "y_hat": y_base})
@@ -822,7 +826,7 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
         lrp = cc_stack(sd, f"lrp_transforms_prog.{j}.", torch.cat([msup, rh], 1))
         yhat_p.append(rh + 0.5 * torch.tanh(lrp) + yhat_b[j])
     y_prog = torch.cat(yhat_p, 1)
-    xp = g_s(sd, "g_s.1.", y_prog)
+    xp = g_s(sd, "g_s.1." if multiple_decoder else "g_s.", y_prog)                       # :462-466
     x_hats.append(xp.clamp(0, 1) if single else xp)
     lik_all = torch.cat([lik_base] + lik_p, 1)
     out.update({"y_hat": y_prog, "y_prog": y_prog, "mask": torch.cat(masks, 1), "mu": torch.cat(mu_p, 1),
@@ -873,7 +877,7 @@ def scalable_rd_loss(out: dict, target: Tensor, lmbda, weight: float = 255.0 ** 
 
 
 def first_train_step(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, lmbda, *,
-                     single: bool = False, trainable=None, force: Optional[dict] = None) -> dict:
+                     single: bool = False, trainable=None, force: Optional[dict] = None, **variant) -> dict:
     """One optimisation step's forward + backward with every floating-point parameter trainable (``trainable``: a
     predicate on the key name; default all).  Returns the forward outputs (detached), the loss terms and
     {name: gradient} — None where autograd left no gradient (a parameter the pass does not use)."""
@@ -887,7 +891,7 @@ def first_train_step(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
             leaves[k] = v.detach().clone().requires_grad_(True)
     sdt = dict(sd)
     sdt.update(leaves)
-    out = training_forward(sdt, x, qualities, noise_y, noise_z, single=single, force=force)
+    out = training_forward(sdt, x, qualities, noise_y, noise_z, single=single, force=force, **variant)
     crit = scalable_rd_loss(out, x, lmbda)
     crit["loss"].backward()
     det = lambda t: t.detach() if torch.is_tensor(t) else t

@@ -180,7 +180,7 @@ def _plan_of(net):
     return next(p for k, p in net._plans.items() if k[0] == "full_train")
 
 
-def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single):
+def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single, **variant):
     """The oracle's step (pinned to the REFERENCE's own run by tests/test_oracle_golden.py) with the GPU pass's hard
     decisions imposed: a latent within fp32 summation noise of x.5 rounds either way depending on the convolution's
     summation order (|y| reaches 46 with the synthetic weights: 3e-4 absolute noise, a dozen such elements per image), and
@@ -194,7 +194,7 @@ def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single):
         force["mask"] = nchw(pl.mask)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single, force=force), force
+        return O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single, force=force, **variant), force
 
 
 def _decision_audit(net, sd, free, force, tol=1e-3):
@@ -238,7 +238,10 @@ def _compare_grads(net, ref_grads):
         assert torch.isfinite(g).all(), name
         e, rr = float(((g - r) ** 2).sum()), float((r ** 2).sum())
         num, den = num + e, den + rr
-        f = next(f for f in FAMILIES if name.startswith(f))
+        f = next((f for f in FAMILIES if name.startswith(f)), None)
+        if f is None:                                   # single encoder / decoder / hyperprior: "g_a.", "g_s.", ...
+            f = name.split(".")[0] + "."
+            fam.setdefault(f, [0.0, 0.0])
         fam[f][0] += e
         fam[f][1] += rr
         rel = (e / max(rr, 1e-300)) ** 0.5
@@ -397,3 +400,39 @@ def test_first_train_full_size_step_is_reproducible():
         runs.append((float(c["loss"]), flat.clone()))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert tuple(out["x_hat"].shape) == (2, B, 3, 256, 256) and tuple(out["likelihoods"]["y_prog"].shape) == (1, B, 640, 16, 16)
+
+
+@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single"])
+def test_first_train_step_variants_match_reference(name):
+    """The first-stage training plan with a single encoder / decoder / hyperprior (models/__init__.py:11-55;
+    pic.py:285-288,306-311,372,462-466): one g_a with 640 outputs (its last attention block runs 80-dimensional heads), one
+    synthesis pair with 640 outputs, ONE g_s reconstructing both levels (two taped passes, gradients summed).  Loss terms,
+    likelihoods, reconstructions and every gradient against the oracle's step at equal rounding decisions; the oracle's step is
+    the reference's (tests/golden/first_train_variants.npz, CPU suite)."""
+    from vampic.finetune import ScalableRateDistortionLoss
+    from test_oracle_golden import train_fixture_inputs
+    from config_variants import variant_args, oracle_kwargs
+    a = variant_args(name)
+    net = vampic.get_model(a, "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    x, ny, nz = train_fixture_inputs()
+    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior")}
+    for use_graph in (False, True):
+        net.use_graph = use_graph
+        net.zero_grad(set_to_none=True)
+        out = net(x.cuda(), quality=[0, 10], training=True, noise={"y": ny, "z": nz})
+        crit = ScalableRateDistortionLoss(lmbda_list=[0.0055, 0.04], device="cuda")(out, x.cuda())
+        crit["loss"].backward()
+        ref, _ = _forced_oracle_step(sd, net, x, ny, nz, [0, 10], [0.0055, 0.04], False, **kw)
+        for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype"):
+            a_, b_ = float(crit[k].detach().mean()), float(ref["crit"][k].mean())
+            assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(b_)), (k, a_, b_)
+        assert _rel(out["x_hat"], ref["out"]["x_hat"]) <= 1e-4
+        assert _rel(out["likelihoods"]["y"], ref["out"]["likelihoods"]["y"]) <= 1e-4
+        joint, fam, worst = _compare_grads(net, ref["grads"])
+        print(name, f"graph={use_graph}", "joint gradient error", joint, "worst", worst)
+        assert joint <= 2e-4, (joint, fam)
+        for f, v in fam.items():
+            assert v <= 5e-4, (f, v, fam)

@@ -4,6 +4,7 @@ is compared bit-exactly, float tensors with 1e-5 relative slack so that a differ
 (another MKLDNN code path) cannot fail the suite."""
 import json
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -408,3 +409,38 @@ def test_oracle_reproduces_reference_trained_like_profile():
                 assert np.array_equal(thr, gold[tag + "_thr"]), tag
             assert abs(O.psnr(x, o["x_hat"]) - scal[tag]["psnr"]) <= 1e-4, tag
             assert abs(O.bpp(o["likelihoods"], npix) - scal[tag]["bpp"]) <= 1e-6, tag
+
+
+@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single"])
+def test_oracle_first_train_step_variants_match_reference(name):
+    """First-stage training step with a single encoder / decoder / hyperprior (pic.py:285-288,306-311,372,462-466): the
+    oracle's forward([0, 10], training=True) + ScalableRateDistortionLoss + autograd against the REFERENCE's own run
+    (oracle/gen_golden.py section 13): losses, likelihoods, reconstructions and every sampled gradient."""
+    import vampic
+    from config_variants import variant_args, oracle_kwargs
+    gold = np.load(os.path.join(GOLD, "first_train_variants.npz"))
+    a = variant_args(name)
+    net = vampic.get_model(a, "cpu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    x, ny, nz = train_fixture_inputs()
+    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = O.first_train_step(sd, x, [0, 10], ny, nz, [0.0055, 0.04], **kw)
+    for i, k in enumerate(("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype")):
+        assert abs(float(r["crit"][k].mean()) - gold[name + "_loss"][i]) <= 1e-5 * max(1.0, abs(gold[name + "_loss"][i])), k
+    _close(r["out"]["x_hat"][:, :, :, ::4, ::4], gold[name + "_x_hat"], 2e-5)
+    _close(r["out"]["likelihoods"]["y"], gold[name + "_lik_y"], 2e-5)
+    _close(r["out"]["likelihoods"]["z"], gold[name + "_lik_z"], 2e-5)
+    names = [str(n) for n in gold[name + "_grad_names"]]
+    assert sorted(names) == sorted(k for k, g in r["grads"].items() if g is not None)
+    samples, off = gold[name + "_grad_samples"], 0
+    num = den = 0.0
+    for n_, norm in zip(names, gold[name + "_grad_norms"]):
+        g = r["grads"][n_].reshape(-1)
+        sref = samples[off:off + len(g[::997])]
+        off += len(sref)
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * norm + 1e-9, n_
+        num += float(((g[::997].numpy() - sref).astype(np.float64) ** 2).sum())
+        den += float((sref.astype(np.float64) ** 2).sum())
+    assert off == len(samples) and (num / den) ** 0.5 <= 1e-5
