@@ -72,7 +72,7 @@ def lower_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs: Se
                 # both take bf16x3 planes it is written as planes (one split, by the producer), as in the eval stacks
                 nm = lay[k][d + 1][0]
                 p3 = Co % 8 == 0 and isinstance(m, Ly.Conv2d) and isinstance(nm, Ly.Conv2d) and nm.kernel_size == 3 and \
-                    nm.stride == 1 and ops.wgrad_reads_planes(Ho, Wo) and v0.B * Ho * Wo <= E.P3_MAX_PIXELS
+                    nm.stride == 1 and ops.train_tape_planes(Ho, Wo) and v0.B * Ho * Wo <= E.P3_MAX_PIXELS
                 a = plan.buf3(v0.B, Ho, Wo, Co) if p3 else plan.buf(v0.B, Ho, Wo, Co)
                 probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], a, L.ACT_GELU, preact=z))
                 nxt.append([a])

@@ -438,7 +438,7 @@ def lower_lrp_stacks_train(plan: E.Plan, stacks: Sequence[nn.Sequential], inputs
             z = plan.buf(v0.B, v0.H, v0.W, m.out_channels)
             if d < depth - 1:           # GELU in the epilogue, pre-activation kept as the second output
                 # (as planes where the next layer's convolution and weight gradient both read planes: full_train.lower_stacks_train)
-                p3 = m.out_channels % 8 == 0 and ops.wgrad_reads_planes(v0.H, v0.W) and v0.B * v0.H * v0.W <= E.P3_MAX_PIXELS
+                p3 = m.out_channels % 8 == 0 and ops.train_tape_planes(v0.H, v0.W) and v0.B * v0.H * v0.W <= E.P3_MAX_PIXELS
                 a = plan.buf3(v0.B, v0.H, v0.W, m.out_channels) if p3 else plan.buf(v0.B, v0.H, v0.W, m.out_channels)
                 probs.append(ops.conv_problem(packs[k].f[id(m)], cur[k], a, L.ACT_GELU, preact=z))
                 nxt.append([a])

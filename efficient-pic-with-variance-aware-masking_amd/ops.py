@@ -605,10 +605,17 @@ def wgrad_problems(x_segs: Sequence[View], dy: View, dw: torch.Tensor, db: Optio
 
 def wgrad_reads_planes(H: int, W: int) -> bool:
     """True when the weight gradient of a k3 stride-1 layer on an H x W grid takes the LDS-tiled kernel, which can read its
-    input as bf16x3 planes (``View3``): the taped activations of the slice stacks are then written as planes only."""
-    if os.environ.get("VAMPIC_TRAIN_P3", "1") == "0":        # A/B arm: fp32 activations on the tape everywhere
-        return False
+    input as bf16x3 planes (``View3``)."""
     return split_mode() and bool(L.load().vam_conv_wgrad_lds_grid(int(H), int(W)))
+
+
+def train_tape_planes(H: int, W: int) -> bool:
+    """Policy: write the taped activations of the training slice stacks as bf16x3 planes where forward convolution and
+    weight gradient can both read them.  OFF by default — built, bit-identical (tests/test_gpu_wgrad_lds.py), and measured
+    no faster on the first_train step (interleaved on one box: 140.2 / 140.3 ms with, 140.1 / 139.9 without,
+    gpurun_out/r4_p3o*.log: the forward gains what the 1.5x bytes of the plane stores cost the backward).
+    ``VAMPIC_TRAIN_P3=1`` switches it on."""
+    return os.environ.get("VAMPIC_TRAIN_P3", "0") == "1" and wgrad_reads_planes(H, W)
 
 
 def wgrad_plan(problems: Sequence[L.VamWgrad]):

@@ -64,11 +64,14 @@ def test_slice_stack_backward_with_segmented_input():
                  [(2, 320, 4, 8), (2, 64, 4, 8), (2, 32, 4, 8)], None, 31)
 
 
-def test_slice_stack_backward_on_the_latent_grid_of_the_full_size_step():
-    """The same stack on a 16 x 16 grid (what a 256 x 256 image gives): weight gradients take the LDS-tiled kernel and the
-    intermediate activations travel as bf16x3 planes (forward convolution and weight gradient both read them as planes)."""
+@pytest.mark.parametrize("planes", ["0", "1"])
+def test_slice_stack_backward_on_the_latent_grid_of_the_full_size_step(planes, monkeypatch):
+    """The same stack on a 16 x 16 grid (what a 256 x 256 image gives): weight gradients take the LDS-tiled kernel; with
+    VAMPIC_TRAIN_P3=1 the intermediate activations travel as bf16x3 planes (forward convolution and weight gradient both
+    read them as planes)."""
     from vampic.models import _param_stack
-    assert ops.wgrad_reads_planes(16, 16)
+    monkeypatch.setenv("VAMPIC_TRAIN_P3", planes)
+    assert ops.wgrad_reads_planes(16, 16) and ops.train_tape_planes(16, 16) == (planes == "1")
     _stack_check(_param_stack(320 + 64 + 32, 320), lambda sd, x: O.cc_stack(sd, "m.", x),
                  [(2, 320, 16, 16), (2, 64, 16, 16), (2, 32, 16, 16)], None, 33)
 
@@ -429,7 +432,9 @@ def test_first_train_step_variants_match_reference(name):
         for k in ("loss", "bpp_loss", "bpp_base", "bpp_scalable", "bpp_hype"):
             a_, b_ = float(crit[k].detach().mean()), float(ref["crit"][k].mean())
             assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(b_)), (k, a_, b_)
-        assert _rel(out["x_hat"], ref["out"]["x_hat"]) <= 1e-4
+        # (the synthetic generator's decoder gains are keyed on the dual-decoder names: a single g_s gets the default gain
+        # and its un-clamped training reconstruction reaches 1e6 — fp32 summation noise is 2e-4 of that range)
+        assert _rel(out["x_hat"], ref["out"]["x_hat"]) <= (1e-4 if a.multiple_decoder else 1e-3)
         assert _rel(out["likelihoods"]["y"], ref["out"]["likelihoods"]["y"]) <= 1e-4
         joint, fam, worst = _compare_grads(net, ref["grads"])
         print(name, f"graph={use_graph}", "joint gradient error", joint, "worst", worst)
