@@ -23,15 +23,15 @@ import torch
 
 _SKIP = ("pedestal", "bound", "target", "relative_position_index", "_offset",
          "_quantized_cdf", "_cdf_length", "scale_table", "scale_bound")
-_DECONV = re.compile(r"^g_s\.\d+\.(1|3|6|8)\.weight$")
+_DECONV = re.compile(r"^g_s\.(\d+\.)?(1|3|6|8)\.weight$")
 # per-layer gains that keep the random-weight network in a sane numeric range
 _GAINS = [(re.compile(p), g) for p, g in (
     (r"^cc_scale_transforms(_prog)?\.\d+\.8\.weight$", 1.5),
     (r"^g_a\.\d+\.7\.weight$", 5.0),
-    (r"^g_s\.\d+\.1\.weight$", 0.06),
-    (r"^g_s\.\d+\.3\.weight$", 0.9),
-    (r"^g_s\.\d+\.6\.weight$", 0.4),
-    (r"^g_s\.\d+\.8\.weight$", 0.08),
+    (r"^g_s\.(\d+\.)?1\.weight$", 0.06),       # (\d+\.)?: a single decoder's layers are named g_s.1.weight, ... — without the gains its
+    (r"^g_s\.(\d+\.)?3\.weight$", 0.9),        # un-clamped training reconstruction reaches 1e6 (round 4)
+    (r"^g_s\.(\d+\.)?6\.weight$", 0.4),
+    (r"^g_s\.(\d+\.)?8\.weight$", 0.08),
 )]
 
 
@@ -112,7 +112,7 @@ def synth_tensor(name: str, like: torch.Tensor, seed: int = 0, profile: str = "d
         b = 0.05 * rn()
         if re.match(r"^cc_scale_transforms(_prog)?\.\d+\.8\.bias$", name):
             b = b + _PROFILE_SCALE_BIAS.get(profile, 1.5)
-        elif re.match(r"^g_s\.\d+\.8\.bias$", name):
+        elif re.match(r"^g_s\.(\d+\.)?8\.bias$", name):
             b = b + 0.5
         return b
     if leaf == "weight":

@@ -150,6 +150,35 @@ def section_rem_no_mu_std(get_model, args):
     np.savez_compressed(os.path.join(GOLD, "rem_train_step_no_mu_std.npz"), **rec)
 
 
+def section_config_variants(get_model, args):
+    """9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each
+    (q = 0 and q = 2.5; REM variants with a checkpoint latent at their first check level).  Weights: the same
+    name-keyed synthetic generator, so the shared modules carry the same values in every variant."""
+    rec, scal = {}, {}
+    x = synth.synth_image(1, 64, 64, seed=2)
+    for name, over in CONFIG_VARIANTS.items():
+        a_ = argparse.Namespace(**{**vars(args), "model": "pic", **over})
+        ref_net = quiet(get_model, a_, "cpu").eval()
+        fill(ref_net, 0)
+        with torch.no_grad():
+            ck = None
+            if a_.model == "rem":
+                ck = ref_net.forward_single_quality(x, quality=a_.check_levels[0], training=False)["y_hat"]
+                rec[f"{name}_ck"] = ck.numpy()
+            for q in (0, 2.5):
+                kw = dict(checkpoint_ref=ck.clone()) if (ck is not None and q > 0) else {}
+                o = ref_net.forward_single_quality(x, quality=q, training=False, **kw)
+                tag = f"{name}_q{q}"
+                rec[tag + "_x_hat"] = o["x_hat"][:, :, ::2, ::2].numpy()
+                rec[tag + "_y_hat"] = o["y_hat"].numpy()
+                mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
+                bits = sum(torch.log(v.double()).sum().item() for v in o["likelihoods"].values()) / (-np.log(2) * 64 * 64)
+                scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
+    np.savez_compressed(os.path.join(GOLD, "config_variants.npz"), **rec)
+    with open(os.path.join(GOLD, "config_variants.json"), "w") as f:
+        json.dump(scal, f, indent=1)
+
+
 TRAIN_VARIANTS = ("single_encoder", "single_decoder", "single_hyperprior", "all_single")
 
 
@@ -229,6 +258,8 @@ def main():
         return section_rem_no_mu_std(get_model, args)
     if os.environ.get("VAMPIC_GOLDEN_ONLY") == "first_train_variants":
         return section_first_train_variants(get_model, args)
+    if os.environ.get("VAMPIC_GOLDEN_ONLY") == "config_variants":
+        return section_config_variants(get_model, args)
     net = quiet(get_model, args, "cpu").eval()
 
     # 1. state_dict manifest
@@ -557,33 +588,7 @@ def main():
     pic.zero_grad(set_to_none=True)
     pic.eval()
 
-    # 9. every constructor flag of models/__init__.py:11-55 away from the README values, one 64x64 image each
-    #    (q = 0 and q = 2.5; REM variants with a checkpoint latent at their first check level).  Weights: the same
-    #    name-keyed synthetic generator, so the shared modules carry the same values in every variant.
-    rec, scal = {}, {}
-    x = synth.synth_image(1, 64, 64, seed=2)
-    for name, over in CONFIG_VARIANTS.items():
-        a_ = argparse.Namespace(**{**vars(args), "model": "pic", **over})
-        ref_net = quiet(get_model, a_, "cpu").eval()
-        fill(ref_net, 0)
-        with torch.no_grad():
-            ck = None
-            if a_.model == "rem":
-                ck = ref_net.forward_single_quality(x, quality=a_.check_levels[0], training=False)["y_hat"]
-                rec[f"{name}_ck"] = ck.numpy()
-            for q in (0, 2.5):
-                kw = dict(checkpoint_ref=ck.clone()) if (ck is not None and q > 0) else {}
-                o = ref_net.forward_single_quality(x, quality=q, training=False, **kw)
-                tag = f"{name}_q{q}"
-                rec[tag + "_x_hat"] = o["x_hat"][:, :, ::2, ::2].numpy()
-                rec[tag + "_y_hat"] = o["y_hat"].numpy()
-                mse = torch.nn.functional.mse_loss(x, o["x_hat"]).item()
-                bits = sum(torch.log(v.double()).sum().item() for v in o["likelihoods"].values()) / (-np.log(2) * 64 * 64)
-                scal[tag] = {"psnr": -10 * np.log10(mse), "bpp": bits}
-    np.savez_compressed(os.path.join(GOLD, "config_variants.npz"), **rec)
-    with open(os.path.join(GOLD, "config_variants.json"), "w") as f:
-        json.dump(scal, f, indent=1)
-
+    section_config_variants(get_model, args)           # 9. constructor-flag variants
     section_trained_like(get_model, args)              # 11. trained-like weight profile (round 4)
     section_rem_no_mu_std(get_model, args)             # 12. REM fine-tune step, mu_std = False (round 4)
     section_first_train_variants(get_model, args)      # 13. first-stage training step, single encoder / decoder / hyperprior (round 4)
