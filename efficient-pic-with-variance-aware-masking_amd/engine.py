@@ -215,11 +215,40 @@ class Plan:
             pend.sort(key=lambda c: (c.kh, c.stride == 2, c.N, c.C, c.B * c.H * c.W))
             self.wgrad(pend, now=True)
 
+    # Weight gradients on their own branch.  Nothing downstream of a layer's weight gradient is on the backward's critical
+    # path (the chain is data gradient -> data gradient), and the slice stacks' launches leave most of the chip idle (8192
+    # pixels: 128 - 256 workgroups): with ``wgrad_branch`` set, a weight-gradient launch that no later step reads (not
+    # ``now``) is recorded on that branch behind an event of the launch that produced its dY, so under capture it becomes a
+    # parallel branch of the hipGraph.  Both operands are buffers that nothing writes after that event (fresh buffers of the
+    # backward, the forward's tape, channel windows of the accumulators that are final by then) and every problem owns its
+    # pixel-split scratch, so the branch needs no other ordering; :meth:`join` (and the end of every :meth:`run_range`)
+    # orders the main branch behind it.
+    wgrad_branch: Optional[int] = None
+
+    def join(self, b: Optional[int]):
+        """The current branch waits for everything recorded on branch ``b`` so far."""
+        if b is None or b == self.cur_branch or b not in self.branch_of:
+            return
+        b0 = self.cur_branch
+        self.branch(b)
+        ev = self.record()
+        self.branch(b0)
+        self.wait(ev)
+
     def wgrad(self, problems: Sequence[L.VamWgrad], now: bool = False):
         """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`).  ``now``: a later step of the plan reads the
-        result (a temporary that is re-indexed / re-parametrised into the gradient): never deferred."""
+        result (a temporary that is re-indexed / re-parametrised into the gradient): never deferred, never on the side branch."""
         if self._wgrad_pending is not None and not now:
             self._wgrad_pending += list(problems)
+            return
+        if self.wgrad_branch is not None and not now and self.cur_branch != self.wgrad_branch and problems:
+            ev, b0 = self.record(), self.cur_branch
+            self.branch(self.wgrad_branch)
+            self.wait(ev)
+            try:
+                self.wgrad(problems, now=True)
+            finally:
+                self.branch(b0)
             return
         lib = L.load()
         for i in range(0, len(problems), L.VAM_MAX_WGRAD_GROUP):
@@ -287,12 +316,18 @@ class Plan:
 
     # ---- execution
     def run(self):
+        self.run_range(0, len(self.steps))
+
+    def run_range(self, a: int, b: int):
+        """Steps [a, b) on the current stream and, for the other branches, on side streams ordered by the recorded events.
+        A range is self-contained (it can be captured as one hipGraph): side streams are forked from the current stream
+        at their first use and joined back at the end, so a wait on an event recorded before ``a`` is already satisfied."""
         main = torch.cuda.current_stream(self.device)
         prof = ops.prof_on()
         if self.n_events == 0 or prof:
             # (event profiler on: one stream, in recording order — a valid topological order — so that a launch's event
             # pair brackets that launch alone and not whatever the other branch runs beside it)
-            for c, s in zip(self.class_of, self.steps):
+            for c, s in zip(self.class_of[a:b], self.steps[a:b]):
                 if isinstance(s, tuple):
                     continue
                 if prof:
@@ -300,27 +335,36 @@ class Plan:
                 s()
             return
         streams = {0: main}
-        for b in set(self.branch_of):
-            if b != 0:
-                if b not in self._side:
-                    self._side[b] = torch.cuda.Stream(device=self.device)
-                streams[b] = self._side[b]
-        events = [torch.cuda.Event() for _ in range(self.n_events)]
+        events: Dict[int, "torch.cuda.Event"] = {}
+        start = None
         cur = 0
         try:
-            for b, c, s in zip(self.branch_of, self.class_of, self.steps):
-                if prof and not isinstance(s, tuple):
-                    ops.prof_set_class(c)
-                if b != cur:
-                    torch.cuda.set_stream(streams[b])
-                    cur = b
+            for i in range(a, b):
+                br, s = self.branch_of[i], self.steps[i]
+                if br not in streams:
+                    if br not in self._side:
+                        self._side[br] = torch.cuda.Stream(device=self.device)
+                    streams[br] = self._side[br]
+                    if start is None:
+                        start = torch.cuda.Event()
+                        start.record(main)       # (main has only advanced since: a later fork point would do as well)
+                    streams[br].wait_event(start)
+                if br != cur:
+                    torch.cuda.set_stream(streams[br])
+                    cur = br
                 if isinstance(s, tuple):
                     if s[0] == "rec":
-                        events[s[1]].record(streams[b])
-                    else:
-                        streams[b].wait_event(events[s[1]])
+                        events[s[1]] = torch.cuda.Event()
+                        events[s[1]].record(streams[br])
+                    elif s[1] in events:
+                        streams[br].wait_event(events[s[1]])
                 else:
                     s()
+            for br, st in streams.items():
+                if br != 0:
+                    e = torch.cuda.Event()
+                    e.record(st)
+                    main.wait_event(e)
         finally:
             torch.cuda.set_stream(main)
 

@@ -20,6 +20,7 @@ per bucket, issued while the rest of the backward runs) hangs on these (sharding
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -33,6 +34,9 @@ from . import ops
 from .ops import View
 
 BUCKET_BYTES = 25 * 1024 * 1024
+WGRAD_BRANCH = 7                # stream branch of the backward plan's weight-gradient launches
+WGRAD_SIDE_DEFAULT = "2"
+GS_BASE_BRANCH = 1              # the base decoder beside the progressive slice chain (forward and backward)
 
 
 # ============================================================================= generic conv stacks with a tape
@@ -314,8 +318,17 @@ class FullTrainPlan:
             for k, i in enumerate(idx):
                 P.call(lambda k=k, i=i, t_l=t_l: ops.ew(L.EW_HTANH_FWD, [t_l[k]["out"], sl(yq, i), zero32], [sl(yb, i)]), "lrp tail")
             self.t_base.append(dict(idx=idx, sup=sup, ms=t_ms, lrp=t_l))
+        # The base reconstruction needs y_hat_base only and nothing of this step needs it: with both levels on the path it
+        # runs on a branch of its own beside the progressive slice chain (ten dependent stacks of five small launches that
+        # leave most of the chip idle) — forward here, backward below.  VAMPIC_TRAIN_OVERLAP=0: one stream as in round 3.
+        overlap = dec_base and dec_prog and os.environ.get("VAMPIC_TRAIN_OVERLAP", "1") == "1"
         if dec_base:
+            if overlap:
+                ev = P.record()
+                P.branch(GS_BASE_BRANCH)
+                P.wait(ev)
             self.t_gs0 = G.lower_g_s_train(P, gs_base, yb, self.x_hat[0], pk(gs_base), clamp=clamp)
+            P.branch(0)
 
         # ---- progressive slices (pic.py:396-457)
         if dec_prog:
@@ -389,6 +402,19 @@ class FullTrainPlan:
 
         # ------------------------------------------------------------------ backward plan
         bw = self.bwd = E.Plan(dev)
+        # weight gradients on a branch of their own (engine.Plan.wgrad_branch).  VAMPIC_WGRAD_SIDE: 0 = one stream as in
+        # round 3, 1 = the entropy-parameter / LRP / hyperprior stacks only, 2 = every transform
+        side = int(os.environ.get("VAMPIC_WGRAD_SIDE", WGRAD_SIDE_DEFAULT))
+        bw.wgrad_branch = WGRAD_BRANCH if side >= 1 else None
+
+        def transform_bwd(fn, *a, **kw):            # g_a / g_s: their launches fill the chip on their own
+            keep_ = bw.wgrad_branch
+            if side < 2:
+                bw.wgrad_branch = None
+            try:
+                return fn(*a, **kw)
+            finally:
+                bw.wgrad_branch = keep_
         bw.keep += [self.flat, self.views]
         self.g_xhat = torch.zeros_like(self.x_hat)
         self.glik = bw.buf(B, h, w, nh * d, zero=True)
@@ -422,11 +448,37 @@ class FullTrainPlan:
                 off += c
             assert off == dx.C
 
+        def gs_base_bwd():
+            g0 = grads
+            if shared_dec:
+                # the same parameters took part in the progressive pass above: this pass writes its gradients into a scratch
+                # copy of the decoder's range of the flat buffer, and ONE element-wise launch adds the two
+                ps = list(gs_base.parameters())
+                pos = {id(p_): i for i, p_ in enumerate(order)}
+                lo_ = offs[pos[id(ps[0])]]
+                hi_ = offs[pos[id(ps[-1])]] + (ps[-1].numel() + 3) // 4 * 4
+                tmp = torch.zeros(hi_ - lo_, **f32)
+                bw.keep.append(tmp)
+                g0 = dict(grads)
+                for p_ in ps:
+                    o_ = offs[pos[id(p_)]] - lo_
+                    g0[id(p_)] = tmp[o_:o_ + p_.numel()].view(p_.shape)
+                self._shared_sum = (self.flat[lo_:hi_], tmp)
+            return transform_bwd(G.lower_g_s_backward, bw, self.t_gs0, self.x_hat[0], self.g_xhat[0], pk(gs_base), g0,
+                                 need_input_grad=True, clamp=clamp)
+
+        d_yb0 = None
         if dec_prog:
             g1 = self.g_xhat[n_rec - 1]
-            d_yp = G.lower_g_s_backward(bw, self.t_gs1, self.x_hat[n_rec - 1], g1, pk(gs_prog), grads, need_input_grad=True, clamp=clamp)
+            d_yp = transform_bwd(G.lower_g_s_backward, bw, self.t_gs1, self.x_hat[n_rec - 1], g1, pk(gs_prog), grads, need_input_grad=True, clamp=clamp)
             if not shared_dec:
                 done(gs_prog)
+            if overlap:                             # the base decoder's backward beside the progressive chain's (see the forward)
+                ev = bw.record()
+                bw.branch(GS_BASE_BRANCH)
+                bw.wait(ev)
+                d_yb0 = gs_base_bwd()
+                bw.branch(0)
             acc(D_yb, d_yp)                                                           # merge: y_hat = r_hat + y_hat_base (pic.py:451)
             dzl = []
             for j in range(ns):
@@ -466,24 +518,13 @@ class FullTrainPlan:
                 scatter(dxm, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []))
                 scatter(dxs_, [(D_sh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_stdp, j - s_, s_), C * s_)] if s_ else []))
         if dec_base:
-            g0 = grads
+            if d_yb0 is None:
+                d_yb0 = gs_base_bwd()
+            else:
+                bw.join(GS_BASE_BRANCH)
             if shared_dec:
-                # the same parameters took part in the progressive pass above: this pass writes its gradients into a scratch
-                # copy of the decoder's range of the flat buffer, and ONE element-wise launch adds the two
-                ps = list(gs_base.parameters())
-                pos = {id(p_): i for i, p_ in enumerate(order)}
-                lo_ = offs[pos[id(ps[0])]]
-                hi_ = offs[pos[id(ps[-1])]] + (ps[-1].numel() + 3) // 4 * 4
-                tmp = torch.zeros(hi_ - lo_, **f32)
-                bw.keep.append(tmp)
-                g0 = dict(grads)
-                for p_ in ps:
-                    o_ = offs[pos[id(p_)]] - lo_
-                    g0[id(p_)] = tmp[o_:o_ + p_.numel()].view(p_.shape)
-                main = self.flat[lo_:hi_]
-            d_yb0 = G.lower_g_s_backward(bw, self.t_gs0, self.x_hat[0], self.g_xhat[0], pk(gs_base), g0, need_input_grad=True,
-                                         clamp=clamp)
-            if shared_dec:
+                bw.join(bw.wgrad_branch)                        # both passes' weight gradients are final
+                main, tmp = self._shared_sum
                 bw.call(lambda: ops.ew(L.EW_AXPY, [ops.flat_view(main), ops.flat_view(tmp)], [ops.flat_view(main)], coef=1.0),
                         "single decoder: sum of the two passes' gradients")
             done(gs_base)
@@ -544,7 +585,7 @@ class FullTrainPlan:
         done(m.h_a)
         acc(D_y, dxy)
         for k, e in enumerate(self.enc):
-            lower_g_a_backward(bw, self.t_ga[k], D_y.window(k * d, d) if me else D_y, pk(e), grads)
+            transform_bwd(lower_g_a_backward, bw, self.t_ga[k], D_y.window(k * d, d) if me else D_y, pk(e), grads)
             done(e)
         # ------------------------------------------------------------------ buckets
         from .sharding import bucket_partition
@@ -654,6 +695,4 @@ class FullTrainPlan:
         return self.views
 
     def _run_bwd_segment(self, a: int, b: int):
-        for s in self.bwd.steps[a:b]:
-            if not isinstance(s, tuple):
-                s()
+        self.bwd.run_range(a, b)        # (joins the weight-gradient branch at the end: a segment ends where a bucket is final)

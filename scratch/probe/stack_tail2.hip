@@ -138,19 +138,25 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
   f32x16 acc4;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc4[r] = 0.f;
-  u32x4 rin[5], rw[2];
+  // weight slabs: slab s is requested at step s - 2 (two register sets, alternating), stored to LDS ring slot s & 1 at step
+  // s, one barrier before its use: two steps of latency hidden
+  u32x4 rin[5], rwA[2], rwB[2];
+  auto w4_of = [&](int it_) { const int nc = it_ / 9, nt = it_ - nc * 9; return P.w4 + (size_t)(nt * 4 + nc) * C_MID * 192; };
   load_in(0, rin);
-  load_w(P.w4, C_MID, rw);
+  load_w(w4_of(0), C_MID, rwA);
+  load_w(w4_of(1), C_MID, rwB);
   __syncthreads();                                             // sMid zeroed
   for (int chunk = 0; chunk < 4; ++chunk) {
     store_in(rin);
     if (chunk + 1 < 4) load_in(chunk + 1, rin);
     for (int tap = 0; tap < 9; ++tap) {
       const int it = chunk * 9 + tap;
-      store_w(it & 1, C_MID, rw);
-      if (it + 1 < 36) {
-        const int nc = (it + 1) / 9, ntap = (it + 1) - nc * 9;
-        load_w(P.w4 + (size_t)(ntap * 4 + nc) * C_MID * 192, C_MID, rw);
+      if (it & 1) {
+        store_w(1, C_MID, rwB);
+        if (it + 2 < 36) load_w(w4_of(it + 2), C_MID, rwB);
+      } else {
+        store_w(0, C_MID, rwA);
+        if (it + 2 < 36) load_w(w4_of(it + 2), C_MID, rwA);
       }
       __syncthreads();                                         // slab `it` (and, at tap 0, the input chunk) is in LDS
       const int ty = tap / 3, tx = tap - ty * 3;
@@ -192,14 +198,18 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
   f32x16 acc5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc5[r] = 0.f;
-  load_w(P.w5, C_OUT, rw);
+  auto w5_of = [&](int it_) { const int nc = it_ / 9, nt = it_ - nc * 9; return P.w5 + (size_t)(nt * 2 + nc) * C_OUT * 192; };
+  load_w(w5_of(0), C_OUT, rwA);
+  load_w(w5_of(1), C_OUT, rwB);
   __syncthreads();                                             // sMid complete; layer-4 slab buffers free
   for (int it = 0; it < 18; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
-    store_w(it & 1, C_OUT, rw);
-    if (it + 1 < 18) {
-      const int nc = (it + 1) / 9, ntap = (it + 1) - nc * 9;
-      load_w(P.w5 + (size_t)(ntap * 2 + nc) * C_OUT * 192, C_OUT, rw);
+    if (it & 1) {
+      store_w(1, C_OUT, rwB);
+      if (it + 2 < 18) load_w(w5_of(it + 2), C_OUT, rwB);
+    } else {
+      store_w(0, C_OUT, rwA);
+      if (it + 2 < 18) load_w(w5_of(it + 2), C_OUT, rwA);
     }
     __syncthreads();
     if (wid < 2) {
@@ -248,7 +258,9 @@ static void split3(float v, unsigned short (&o)[3]) {
 static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
 
 int main(int argc, char** argv) {
-  const int B = argc > 1 ? atoi(argv[1]) : 32, NP = argc > 2 ? atoi(argv[2]) : 2, reps = argc > 3 ? atoi(argv[3]) : 200;
+  const int B = argc > 1 ? atoi(argv[1]) : 32, reps = argc > 3 ? atoi(argv[3]) : 200;
+  int NP = argc > 2 ? atoi(argv[2]) : 2;
+  if (NP < 1 || NP > 8 || B < 1 || B > 64) { printf("usage: stack_tail2 [B 1..64] [problems 1..8] [reps]\n"); return 2; }   // Args holds 8 problems
   unsigned seed = 12345;
   const size_t npx = (size_t)B * HH * WW;
   std::vector<std::vector<float>> xs(NP), w4s(NP), w5s(NP), b4s(NP), b5s(NP);
