@@ -18,6 +18,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence
 
+import contextlib
 import ctypes as C
 import os
 import torch
@@ -234,6 +235,25 @@ class Plan:
         ev = self.record()
         self.branch(b0)
         self.wait(ev)
+
+    wgrad_units = False       # whole gradient sub-chains (launch + re-parametrisation / un-padding) on the branch as well
+
+    @contextlib.contextmanager
+    def off_path(self):
+        """Steps recorded inside go to the weight-gradient branch (when there is one and ``wgrad_units`` is on), behind
+        everything recorded so far on the current branch: for a sub-chain that ENDS in parameter gradients — a ``now``
+        weight-gradient launch into a temporary plus the step that re-indexes it, a bias-gradient column sum — which nothing
+        later on the current branch reads."""
+        if self.wgrad_branch is None or not self.wgrad_units or self.cur_branch == self.wgrad_branch:
+            yield
+            return
+        ev, b0 = self.record(), self.cur_branch
+        self.branch(self.wgrad_branch)
+        self.wait(ev)
+        try:
+            yield
+        finally:
+            self.branch(b0)
 
     def wgrad(self, problems: Sequence[L.VamWgrad], now: bool = False):
         """Grouped weight-gradient launches (pre-marshalled like :meth:`conv`).  ``now``: a later step of the plan reads the

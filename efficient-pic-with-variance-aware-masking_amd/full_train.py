@@ -35,7 +35,7 @@ from .ops import View
 
 BUCKET_BYTES = 25 * 1024 * 1024
 WGRAD_BRANCH = 7                # stream branch of the backward plan's weight-gradient launches
-WGRAD_SIDE_DEFAULT = "2"
+WGRAD_SIDE_DEFAULT = "3"
 GS_BASE_BRANCH = 1              # the base decoder beside the progressive slice chain (forward and backward)
 
 
@@ -185,12 +185,12 @@ def _conv5_bwd(bw, pk, r: dict, dy: View, grads, keep: list) -> Optional[View]:
         t16 = torch.zeros((n, 16, 3, 3), dtype=torch.float32, device=gw.device)
         g6 = torch.zeros((n, 3, 6, 6), dtype=torch.float32, device=gw.device)
         keep += [t16, g6]
-        bw.wgrad(ops.wgrad_problems([x], dy, t16, gb), now=True)          # t16 is re-indexed into gw right below
-
         def scatter():          # captured step: strided copies between pre-allocated buffers, no temporaries
             g6.view(n, 3, 3, 2, 3, 2).copy_(t16[:, :12].view(n, 2, 2, 3, 3, 3).permute(0, 3, 4, 1, 5, 2))
             gw.copy_(g6[:, :, :5, :5])
-        bw.call(scatter, "first-layer weight gradient: s2d -> 5x5")
+        with bw.off_path():
+            bw.wgrad(ops.wgrad_problems([x], dy, t16, gb), now=True)      # t16 is re-indexed into gw right below
+            bw.call(scatter, "first-layer weight gradient: s2d -> 5x5")
         return None
     bw.wgrad(ops.wgrad_problems([x], dy, gw, gb, stride=2))
     dx = bw.buf(x.B, x.H, x.W, x.C)
@@ -260,8 +260,14 @@ class FullTrainPlan:
 
         # ------------------------------------------------------------------ forward plan
         P = self.plan = E.Plan(dev)
-        for mod in mods:
+        pack_side = os.environ.get("VAMPIC_TRAIN_OVERLAP", "1") == "1"
+        for mod in self.enc:                                     # the analysis transforms' packs first ...
             self.pk[id(mod)].record_refresh(P)
+        if pack_side:                                            # ... everything else's beside g_a (joined in front of h_a)
+            P.branch(WGRAD_BRANCH)
+        for mod in mods[len(self.enc):]:
+            self.pk[id(mod)].record_refresh(P)
+        P.branch(0)
         self.x_in = torch.empty((B, 3, H, W), **f32)
         n_rec = (1 if dec_base else 0) + (1 if dec_prog else 0)
         self.x_hat = torch.empty((n_rec, B, 3, H, W), **f32)
@@ -271,6 +277,7 @@ class FullTrainPlan:
         y = self.y = P.buf(B, h, w, 2 * d)
         self.t_ga = [lower_g_a_train(P, e, x_s2d, y.window(k * d, d) if me else y, pk(e)) for k, e in enumerate(self.enc)]
 
+        P.join(WGRAD_BRANCH)
         z = self.z = P.buf(B, h // 4, w // 4, m.N)
         self.t_ha = lower_stacks_train(P, [m.h_a], [[y]], [z], [pk(m.h_a)])
         self.z_hat, self.z_lik, self.noise_z = (P.buf(B, h // 4, w // 4, m.N) for _ in range(3))
@@ -403,9 +410,11 @@ class FullTrainPlan:
         # ------------------------------------------------------------------ backward plan
         bw = self.bwd = E.Plan(dev)
         # weight gradients on a branch of their own (engine.Plan.wgrad_branch).  VAMPIC_WGRAD_SIDE: 0 = one stream as in
-        # round 3, 1 = the entropy-parameter / LRP / hyperprior stacks only, 2 = every transform
+        # round 3, 1 = the entropy-parameter / LRP / hyperprior stacks only, 2 = every transform, 3 = also the GDN / bias /
+        # first-layer gradient sub-chains (engine.Plan.off_path)
         side = int(os.environ.get("VAMPIC_WGRAD_SIDE", WGRAD_SIDE_DEFAULT))
         bw.wgrad_branch = WGRAD_BRANCH if side >= 1 else None
+        bw.wgrad_units = side >= 3
 
         def transform_bwd(fn, *a, **kw):            # g_a / g_s: their launches fill the chip on their own
             keep_ = bw.wgrad_branch

@@ -347,16 +347,18 @@ def _deconv_bwd(bw, pk, r: dict, dy: View, grads, need_dx: bool = True) -> Optio
         bw.wgrad(ops.wgrad_problems([dy], x, gw, None, stride=2))
         wsp = ops.colsum_workspace(dy)
         bw.keep.append(wsp)
-        bw.call(lambda: ops.colsum(dy, gb, wsp), "deconv bias grad")
+        with bw.off_path():
+            bw.call(lambda: ops.colsum(dy, gb, wsp), "deconv bias grad")
     else:                                            # zero-padded 3-channel output gradient
         tw = torch.zeros((ci, dy.C, 5, 5), dtype=torch.float32, device=gw.device)
         tb = torch.zeros((dy.C,), dtype=torch.float32, device=gw.device)
         wsp = ops.colsum_workspace(dy)
         bw.keep += [tw, tb, wsp]
-        bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2), now=True)      # tw is un-padded into gw right below
-        # (torch.mul(.., 1.0, out=..) instead of a contiguous copy_: an element-wise KERNEL node under graph capture, not a
-        # device-to-device memcpy node — see vam_memset_zero for what a non-kernel node did in these graphs)
-        bw.call(lambda: (ops.colsum(dy, tb, wsp), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
+        with bw.off_path():
+            bw.wgrad(ops.wgrad_problems([dy], x, tw, None, stride=2), now=True)      # tw is un-padded into gw right below
+            # (torch.mul(.., 1.0, out=..) instead of a contiguous copy_: an element-wise KERNEL node under graph capture, not a
+            # device-to-device memcpy node — see vam_memset_zero for what a non-kernel node did in these graphs)
+            bw.call(lambda: (ops.colsum(dy, tb, wsp), gw.copy_(tw[:, :co]), torch.mul(tb[:co], 1.0, out=gb)), "deconv bias grad + unpad")
     if not need_dx:
         return None
     dx = bw.buf(x.B, x.H, x.W, ci)
@@ -375,11 +377,12 @@ def _gdn_bwd(bw, pk, r: dict, dy: View, grads) -> View:
     tg = torch.zeros((C_, C_), dtype=torch.float32, device=x.buf.device)
     tb = torch.zeros((C_,), dtype=torch.float32, device=x.buf.device)
     bw.keep += [tg, tb]
-    bw.wgrad(ops.wgrad_problems([x2], s, tg, tb), now=True)           # d gamma' [j][i] = sum dn_j x_i^2 ; d beta' = sum dn (read right below)
     gg, gbeta = grads[id(g.gamma)], grads[id(g.beta)]
-    bw.call(lambda: (ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.gamma.detach()), ops.flat_view(tg)], [ops.flat_view(gg)], coef=_GAMMA_BOUND),
-                     ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.beta.detach()), ops.flat_view(tb)], [ops.flat_view(gbeta)], coef=_BETA_BOUND)),
-            "NonNegativeParametrizer backward")
+    with bw.off_path():                   # nothing on the data-gradient path reads gamma's / beta's gradients
+        bw.wgrad(ops.wgrad_problems([x2], s, tg, tb), now=True)       # d gamma' [j][i] = sum dn_j x_i^2 ; d beta' = sum dn (read right below)
+        bw.call(lambda: (ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.gamma.detach()), ops.flat_view(tg)], [ops.flat_view(gg)], coef=_GAMMA_BOUND),
+                         ops.ew(L.EW_REPARAM_BWD, [ops.flat_view(g.beta.detach()), ops.flat_view(tb)], [ops.flat_view(gbeta)], coef=_BETA_BOUND)),
+                "NonNegativeParametrizer backward")
     return dx
 
 
