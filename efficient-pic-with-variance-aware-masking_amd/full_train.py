@@ -218,9 +218,7 @@ class FullTrainPlan:
 
     def __init__(self, m, B: int, H: int, W: int, mode: str, base_only: bool, device, trainable_ids: Optional[set] = None):
         assert mode in ("multi", "single") and not (mode == "multi" and base_only)
-        if not (m.all_scalable and m.delta_encode and m.total_mu_rep):
-            raise NotImplementedError("the first-stage training plan is built for all_scalable, delta_encode, total_mu_rep (the "
-                                      "README values); the encoder / decoder / hyperprior may each be single or dual")
+        delta, mu_rep, scal = bool(m.delta_encode), bool(m.total_mu_rep), bool(m.all_scalable)
         me, md, mh = bool(m.multiple_encoder), bool(m.multiple_decoder), bool(m.multiple_hyperprior)
         self.m, self.B, self.H, self.W, self.mode, self.base_only = m, B, H, W, mode, base_only
         self.device = torch.device(device)
@@ -340,31 +338,47 @@ class FullTrainPlan:
         # ---- progressive slices (pic.py:396-457)
         if dec_prog:
             mh1, sh1 = means_h.window(d, d), scales_h.window(d, d)
-            self.mu_p, self.std_p, mu_tot = P.buf(B, h, w, d), P.buf(B, h, w, d), P.buf(B, h, w, d)
+            self.mu_p, self.std_p = P.buf(B, h, w, d), P.buf(B, h, w, d)
+            mu_tot = P.buf(B, h, w, d) if mu_rep else self.mu_p      # pic.py:416: mu_total = mu (+ y_hat_base with total_mu_rep)
             sp = m.support_progressive_slices
-            y_top, y_sub = y.window(d, d), y.window(0, d)
+            y_top, y_sub = y.window(d, d), (y.window(0, d) if delta else None)      # pic.py:397-398: r = y_top - y_base under delta_encode
             self.t_chain = []
-            for j in range(ns):
-                s_ = min(sp, j)
-                ms = [mh1, sl(yb, j)] + ([sl(mu_tot, j - s_, s_)] if s_ else [])
-                ss = [sh1, sl(yb, j)] + ([sl(self.std_p, j - s_, s_)] if s_ else [])
-                st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
-                t_ = lower_stacks_train(P, st, [ms, ss], [sl(self.mu_p, j), sl(self.std_p, j)], [pk(s) for s in st])
-                P.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)), "mu_total")       # pic.py:416
-                self.t_chain.append(dict(j=j, s=s_, t=t_, msup=ms))
             self.mask = P.buf(B, h, w, d)
             rq = self.rq = P.buf(B, h, w, d)
             yp = self.y_prog = P.buf(B, h, w, d)
-            P.call(lambda: ops.variance_mask(self.std_p, self.pr, self.mask, n_slice=ns), "variance mask")   # pic.py:430
-            P.call(lambda: ops.gauss_tail(y_top, self.mu_p, self.std_p, y2=y_sub, mask=self.mask, yhat=rq, lik=junk), "quantise (prog)")
             nz_p = self.noise_y.window(d, d)
+            lst = [m.lrp_transforms_prog[j] for j in range(ns)]
+            # all_scalable (pic.py:400-401): the supports of slice j are mu_total / std_total of the slices before it, so the
+            # (mu, sigma) chain runs through all ten slices before anything is quantised; without it they are the DECODED
+            # slices, and each slice is finished (mask, quantisation, LRP, merge) before the next one's stacks run
+            sup_m, sup_s = (mu_tot, self.std_p) if scal else (yp, yp)
+            self.t_lrp_p = []
+            for j in range(ns):
+                s_ = min(sp, j)
+                ms = [mh1, sl(yb, j)] + ([sl(sup_m, j - s_, s_)] if s_ else [])
+                ss = [sh1, sl(yb, j)] + ([sl(sup_s, j - s_, s_)] if s_ else [])
+                st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
+                t_ = lower_stacks_train(P, st, [ms, ss], [sl(self.mu_p, j), sl(self.std_p, j)], [pk(s) for s in st])
+                if mu_rep and scal:
+                    P.call(lambda j=j: ops.add(sl(self.mu_p, j), sl(yb, j), sl(mu_tot, j)), "mu_total")   # pic.py:416
+                self.t_chain.append(dict(j=j, s=s_, t=t_, msup=ms))
+                if not scal:
+                    P.call(lambda j=j: ops.variance_mask(sl(self.std_p, j), self.pr, sl(self.mask, j), n_slice=1), "variance mask")
+                    P.call(lambda j=j: ops.gauss_tail(sl(y_top, j), sl(self.mu_p, j), sl(self.std_p, j), y2=sl(y_sub, j) if delta else None,
+                                                      mask=sl(self.mask, j), yhat=sl(rq, j), lik=sl(junk, j)), "quantise (prog)")
+                    (tl,) = lower_stacks_train(P, [lst[j]], [ms + [sl(rq, j)]], [None], [pk(lst[j])])
+                    self.t_lrp_p.append(tl)
+                    P.call(lambda j=j, tl=tl: ops.ew(L.EW_HTANH_FWD, [tl["out"], sl(rq, j), sl(yb, j)], [sl(yp, j)]), "lrp tail (prog)")
+            if scal:
+                P.call(lambda: ops.variance_mask(self.std_p, self.pr, self.mask, n_slice=ns), "variance mask")   # pic.py:430
+                P.call(lambda: ops.gauss_tail(y_top, self.mu_p, self.std_p, y2=y_sub, mask=self.mask, yhat=rq, lik=junk), "quantise (prog)")
             P.call(lambda: ops.gauss_train(y_top, self.mu_p, self.std_p, nz_p, y2=y_sub, mask=self.mask, lik=self.lik.window(d, d)),
                    "noise likelihood (prog)")
-            lst = [m.lrp_transforms_prog[j] for j in range(ns)]
-            self.t_lrp_p = lower_stacks_train(P, lst, [self.t_chain[j]["msup"] + [sl(rq, j)] for j in range(ns)], [None] * ns,
-                                              [pk(s) for s in lst])
-            for j in range(ns):
-                P.call(lambda j=j: ops.ew(L.EW_HTANH_FWD, [self.t_lrp_p[j]["out"], sl(rq, j), sl(yb, j)], [sl(yp, j)]), "lrp tail (prog)")
+            if scal:
+                self.t_lrp_p = lower_stacks_train(P, lst, [self.t_chain[j]["msup"] + [sl(rq, j)] for j in range(ns)], [None] * ns,
+                                                  [pk(s) for s in lst])
+                for j in range(ns):
+                    P.call(lambda j=j: ops.ew(L.EW_HTANH_FWD, [self.t_lrp_p[j]["out"], sl(rq, j), sl(yb, j)], [sl(yp, j)]), "lrp tail (prog)")
             self.t_gs1 = G.lower_g_s_train(P, gs_prog, yp, self.x_hat[n_rec - 1], pk(gs_prog), clamp=clamp)
 
         # ------------------------------------------------------------------ parameters and the flat gradient buffer
@@ -375,9 +389,12 @@ class FullTrainPlan:
         if dec_prog:
             if not shared_dec:
                 add(gs_prog)
-            for j in range(ns):
-                add(m.lrp_transforms_prog[j])
+            if scal:
+                for j in range(ns):
+                    add(m.lrp_transforms_prog[j])
             for j in range(ns - 1, -1, -1):
+                if not scal:
+                    add(m.lrp_transforms_prog[j])
                 add(m.cc_mean_transforms_prog[j])
                 add(m.cc_scale_transforms_prog[j])
         if dec_base:
@@ -488,44 +505,80 @@ class FullTrainPlan:
                 bw.wait(ev)
                 d_yb0 = gs_base_bwd()
                 bw.branch(0)
-            acc(D_yb, d_yp)                                                           # merge: y_hat = r_hat + y_hat_base (pic.py:451)
-            dzl = []
-            for j in range(ns):
-                zt = self.t_lrp_p[j]["out"]
-                o = bw.buf(zt.B, zt.H, zt.W, zt.C)
-                bw.call(lambda j=j, zt=zt, o=o: ops.ew(L.EW_HTANH_BWD, [zt, sl(d_yp, j)], [o]), "lrp tail bwd")
-                dzl.append(o)
-            lst = [m.lrp_transforms_prog[j] for j in range(ns)]
-            dxs = lower_stacks_backward(bw, self.t_lrp_p, dzl, [pk(s) for s in lst], grads)
-            for s in lst:
-                done(s)
-            d_rq = bw.buf(B, h, w, d)
-            for j in range(ns):
-                s_ = self.t_chain[j]["s"]
-                scatter(dxs[j], [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []) + [(None, C)])
-                bw.call(lambda j=j, dx=dxs[j]: ops.ew(L.EW_AXPY, [sl(d_yp, j), dx.window(dx.C - C, C)], [sl(d_rq, j)], coef=1.0), "d rq")
-            # likelihood + straight-through rounding of the ten progressive slices, one launch each
-            dmu_l, dsg_l = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
-            bw.call(lambda: ops.gauss_train(y_top, self.mu_p, self.std_p, nz_p, y2=y_sub, mask=self.mask,
-                                            grad_lik=self.glik.window(d, d), dmu=dmu_l, dsigma=dsg_l), "likelihood backward (prog)")
-            d_r, G_mu = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
-            bw.call(lambda: ops.ew(L.EW_MASK_SPLIT, [d_rq, self.mask], [d_r, G_mu]), "straight-through rounding under the mask")
-            acc(G_mu, dmu_l)                                                          # dL/dmu_p before the chain
-            acc(d_r, dmu_l, -1.0)                                                     # dL/dr = d rq * m - dmu_lik
-            acc(D_y.window(d, d), d_r)
-            acc(D_y.window(0, d), d_r, -1.0)                                          # delta_encode: r = y_top - y_sub
-            for j in range(ns - 1, -1, -1):
-                rec = self.t_chain[j]
-                s_ = rec["s"]
-                acc(sl(G_mu, j), sl(D_mutot, j))                                      # mu_total_j = mu_j + y_hat_base_j
-                acc(sl(D_yb, j), sl(D_mutot, j))
-                acc(sl(dsg_l, j), sl(D_stdp, j))
-                st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
-                dxm, dxs_ = lower_stacks_backward(bw, rec["t"], [sl(G_mu, j), sl(dsg_l, j)], [pk(s) for s in st], grads)
-                done(st[0])
-                done(st[1])
-                scatter(dxm, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []))
-                scatter(dxs_, [(D_sh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_stdp, j - s_, s_), C * s_)] if s_ else []))
+            if scal:
+                acc(D_yb, d_yp)                                                       # merge: y_hat = r_hat + y_hat_base (pic.py:451)
+                dzl = []
+                for j in range(ns):
+                    zt = self.t_lrp_p[j]["out"]
+                    o = bw.buf(zt.B, zt.H, zt.W, zt.C)
+                    bw.call(lambda j=j, zt=zt, o=o: ops.ew(L.EW_HTANH_BWD, [zt, sl(d_yp, j)], [o]), "lrp tail bwd")
+                    dzl.append(o)
+                lst = [m.lrp_transforms_prog[j] for j in range(ns)]
+                dxs = lower_stacks_backward(bw, self.t_lrp_p, dzl, [pk(s) for s in lst], grads)
+                for s in lst:
+                    done(s)
+                d_rq = bw.buf(B, h, w, d)
+                for j in range(ns):
+                    s_ = self.t_chain[j]["s"]
+                    scatter(dxs[j], [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []) + [(None, C)])
+                    bw.call(lambda j=j, dx=dxs[j]: ops.ew(L.EW_AXPY, [sl(d_yp, j), dx.window(dx.C - C, C)], [sl(d_rq, j)], coef=1.0), "d rq")
+                # likelihood + straight-through rounding of the ten progressive slices, one launch each
+                dmu_l, dsg_l = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                bw.call(lambda: ops.gauss_train(y_top, self.mu_p, self.std_p, nz_p, y2=y_sub, mask=self.mask,
+                                                grad_lik=self.glik.window(d, d), dmu=dmu_l, dsigma=dsg_l), "likelihood backward (prog)")
+                d_r, G_mu = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                bw.call(lambda: ops.ew(L.EW_MASK_SPLIT, [d_rq, self.mask], [d_r, G_mu]), "straight-through rounding under the mask")
+                acc(G_mu, dmu_l)                                                          # dL/dmu_p before the chain
+                acc(d_r, dmu_l, -1.0)                                                     # dL/dr = d rq * m - dmu_lik
+                acc(D_y.window(d, d), d_r)
+                if delta:
+                    acc(D_y.window(0, d), d_r, -1.0)                                      # delta_encode: r = y_top - y_sub
+                for j in range(ns - 1, -1, -1):
+                    rec = self.t_chain[j]
+                    s_ = rec["s"]
+                    acc(sl(G_mu, j), sl(D_mutot, j))                                      # mu_total_j = mu_j + y_hat_base_j
+                    if mu_rep:
+                        acc(sl(D_yb, j), sl(D_mutot, j))
+                    acc(sl(dsg_l, j), sl(D_stdp, j))
+                    st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
+                    dxm, dxs_ = lower_stacks_backward(bw, rec["t"], [sl(G_mu, j), sl(dsg_l, j)], [pk(s) for s in st], grads)
+                    done(st[0])
+                    done(st[1])
+                    scatter(dxm, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_mutot, j - s_, s_), C * s_)] if s_ else []))
+                    scatter(dxs_, [(D_sh.window(d, d), d), (sl(D_yb, j), C)] + ([(sl(D_stdp, j - s_, s_), C * s_)] if s_ else []))
+            else:
+                # all_scalable off: slice j's stacks and LRP read the DECODED slices before it, so dL/dy_hat_j collects the
+                # input gradients of the later slices before slice j's own backward runs (d_yp is accumulated in place:
+                # it is the data gradient g_s handed back, no weight gradient reads it)
+                dmu_l, dsg_l = bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                bw.call(lambda: ops.gauss_train(y_top, self.mu_p, self.std_p, nz_p, y2=y_sub, mask=self.mask,
+                                                grad_lik=self.glik.window(d, d), dmu=dmu_l, dsigma=dsg_l), "likelihood backward (prog)")
+                d_rq, d_r, G_mu = bw.buf(B, h, w, d), bw.buf(B, h, w, d), bw.buf(B, h, w, d)
+                for j in range(ns - 1, -1, -1):
+                    rec = self.t_chain[j]
+                    s_ = rec["s"]
+                    hist = [(sl(d_yp, j - s_, s_), C * s_)] if s_ else []
+                    acc(sl(D_yb, j), sl(d_yp, j))                                     # merge: y_hat_j = r_hat_j + lrp_j + y_hat_base_j
+                    zt = self.t_lrp_p[j]["out"]
+                    dz = bw.buf(zt.B, zt.H, zt.W, zt.C)
+                    bw.call(lambda j=j, zt=zt, dz=dz: ops.ew(L.EW_HTANH_BWD, [zt, sl(d_yp, j)], [dz]), "lrp tail bwd")
+                    (dx,) = lower_stacks_backward(bw, [self.t_lrp_p[j]], [dz], [pk(m.lrp_transforms_prog[j])], grads)
+                    done(m.lrp_transforms_prog[j])
+                    scatter(dx, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + hist + [(None, C)])
+                    bw.call(lambda j=j, dx=dx: ops.ew(L.EW_AXPY, [sl(d_yp, j), dx.window(dx.C - C, C)], [sl(d_rq, j)], coef=1.0), "d rq")
+                    bw.call(lambda j=j: ops.ew(L.EW_MASK_SPLIT, [sl(d_rq, j), sl(self.mask, j)], [sl(d_r, j), sl(G_mu, j)]),
+                            "straight-through rounding under the mask")
+                    acc(sl(G_mu, j), sl(dmu_l, j))
+                    acc(sl(d_r, j), sl(dmu_l, j), -1.0)
+                    acc(sl(D_y.window(d, d), j), sl(d_r, j))
+                    if delta:
+                        acc(sl(D_y.window(0, d), j), sl(d_r, j), -1.0)
+                    st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
+                    dxm, dxs_ = lower_stacks_backward(bw, rec["t"], [sl(G_mu, j), sl(dsg_l, j)], [pk(s) for s in st], grads)
+                    done(st[0])
+                    done(st[1])
+                    scatter(dxm, [(D_mh.window(d, d), d), (sl(D_yb, j), C)] + hist)
+                    scatter(dxs_, [(D_sh.window(d, d), d), (sl(D_yb, j), C)] + hist)
         if dec_base:
             if d_yb0 is None:
                 d_yb0 = gs_base_bwd()

@@ -179,7 +179,7 @@ def section_config_variants(get_model, args):
         json.dump(scal, f, indent=1)
 
 
-TRAIN_VARIANTS = ("single_encoder", "single_decoder", "single_hyperprior", "all_single")
+TRAIN_VARIANTS = ("single_encoder", "single_decoder", "single_hyperprior", "all_single", "no_delta_no_mu_rep", "not_all_scalable")
 
 
 def section_first_train_variants(get_model, args):

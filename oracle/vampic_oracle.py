@@ -753,8 +753,9 @@ def _ste_forced(x: Tensor, q: Optional[Tensor]) -> Tensor:
 def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Tensor, noise_z: Tensor, *,
                      single: bool = False, div: int = 320, chunk: int = 32, max_support: int = 5,
                      prog_support: int = 5, force: Optional[dict] = None, multiple_encoder: bool = True,
-                     multiple_decoder: bool = True, multiple_hyperprior: bool = True) -> dict:
-    """Training-mode forward with delta_encode, total_mu_rep, all_scalable as in the README configuration; the encoder /
+                     multiple_decoder: bool = True, multiple_hyperprior: bool = True, delta_encode: bool = True,
+                     total_mu_rep: bool = True, all_scalable: bool = True) -> dict:
+    """Training-mode forward; delta_encode / total_mu_rep / all_scalable (pic.py:397-405,416) default to the README values; the encoder /
     decoder / hyperprior may each be single (pic.py:285-288,306-311,372,462-466: one g_a with M outputs, one g_s used for
     both reconstructions, one synthesis pair with M outputs).  ``single`` = False: ``forward(x, quality=[0, q])`` — both decoders, no clamp, likelihoods
     {"y": base, "y_prog": [1, B, 640] = base AND progressive (pic.py:389-390,471-472), "z"}.  ``single`` = True:
@@ -809,13 +810,14 @@ def training_forward(sd: SD, x: Tensor, qualities: Sequence[float], noise_y: Ten
         return out
     mu_tot, std_tot, lik_p, yhat_p, masks, mu_p, std_p = [], [], [], [], [], [], []
     for j in range(ns0):                                                                 # :396-457
-        r = ys[ns0 + j] - ys[j]
+        r = ys[ns0 + j] - ys[j] if delta_encode else ys[ns0 + j]                         # :397-398
         s = min(prog_support, j)
-        msup = torch.cat([means_h[:, div:], yhat_b[j]] + mu_tot[j - s:j], 1)
-        ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + std_tot[j - s:j], 1)
+        sup_m, sup_s = (mu_tot, std_tot) if all_scalable else (yhat_p, yhat_p)           # :400-401
+        msup = torch.cat([means_h[:, div:], yhat_b[j]] + sup_m[j - s:j], 1)
+        ssup = torch.cat([scales_h[:, div:], yhat_b[j]] + sup_s[j - s:j], 1)
         mu = cc_stack(sd, f"cc_mean_transforms_prog.{j}.", msup)
         sc = cc_stack(sd, f"cc_scale_transforms_prog.{j}.", ssup)
-        mu_tot.append(mu + yhat_b[j])
+        mu_tot.append(mu + yhat_b[j] if total_mu_rep else mu)                            # :416
         std_tot.append(sc)
         mu_p.append(mu)
         std_p.append(sc)

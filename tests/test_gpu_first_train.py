@@ -195,9 +195,19 @@ def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single, **variant)
     if not pl.base_only:
         force["prog_sym"] = torch.round(nchw(pl.rq) - nchw(pl.mu_p))
         force["mask"] = nchw(pl.mask)
+    # the eager and the hipGraph pass of one test take the same decisions (same kernels, same order): one oracle step serves both
+    key = (id(sd), len(sd), float(x.double().sum()), tuple(qualities), str(lmbda), single, tuple(sorted(variant.items())))
+    hit = _ORACLE_CACHE.get("last")
+    if hit is not None and hit[0] == key and all(torch.equal(hit[2][k], force[k]) for k in force):
+        return hit[1], force
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single, force=force, **variant), force
+        ref = O.first_train_step(sd, x, qualities, ny, nz, lmbda, single=single, force=force, **variant)
+    _ORACLE_CACHE["last"] = (key, ref, force)
+    return ref, force
+
+
+_ORACLE_CACHE: dict = {}
 
 
 def _decision_audit(net, sd, free, force, tol=1e-3):
@@ -405,7 +415,7 @@ def test_first_train_full_size_step_is_reproducible():
     assert tuple(out["x_hat"].shape) == (2, B, 3, 256, 256) and tuple(out["likelihoods"]["y_prog"].shape) == (1, B, 640, 16, 16)
 
 
-@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single"])
+@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single", "no_delta_no_mu_rep", "not_all_scalable"])
 def test_first_train_step_variants_match_reference(name):
     """The first-stage training plan with a single encoder / decoder / hyperprior (models/__init__.py:11-55;
     pic.py:285-288,306-311,372,462-466): one g_a with 640 outputs (its last attention block runs 80-dimensional heads), one
@@ -421,7 +431,8 @@ def test_first_train_step_variants_match_reference(name):
     net.load_state_dict(sd)
     net = net.cuda().train()
     x, ny, nz = train_fixture_inputs()
-    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior")}
+    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior", "delta_encode",
+                                                         "total_mu_rep", "all_scalable")}
     for use_graph in (False, True):
         net.use_graph = use_graph
         net.zero_grad(set_to_none=True)

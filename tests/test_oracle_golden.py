@@ -411,7 +411,7 @@ def test_oracle_reproduces_reference_trained_like_profile():
             assert abs(O.bpp(o["likelihoods"], npix) - scal[tag]["bpp"]) <= 1e-6, tag
 
 
-@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single"])
+@pytest.mark.parametrize("name", ["single_encoder", "single_decoder", "single_hyperprior", "all_single", "no_delta_no_mu_rep", "not_all_scalable"])
 def test_oracle_first_train_step_variants_match_reference(name):
     """First-stage training step with a single encoder / decoder / hyperprior (pic.py:285-288,306-311,372,462-466): the
     oracle's forward([0, 10], training=True) + ScalableRateDistortionLoss + autograd against the REFERENCE's own run
@@ -423,7 +423,8 @@ def test_oracle_first_train_step_variants_match_reference(name):
     net = vampic.get_model(a, "cpu")
     sd = synth.synth_state_dict(net.state_dict(), seed=0)
     x, ny, nz = train_fixture_inputs()
-    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior")}
+    kw = {k: v for k, v in oracle_kwargs(a).items() if k in ("multiple_encoder", "multiple_decoder", "multiple_hyperprior", "delta_encode",
+                                                         "total_mu_rep", "all_scalable")}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         r = O.first_train_step(sd, x, [0, 10], ny, nz, [0.0055, 0.04], **kw)
