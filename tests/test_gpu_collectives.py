@@ -96,3 +96,75 @@ def test_flat_clip_matches_torch_clip():
     # a frozen subset takes torch's own routine and still clips
     list(net.parameters())[0].grad = None
     assert float(ft.clip_grad_norm_(net, 1.0)) <= 1.0 + 1e-4
+
+
+def _two_rank_worker(rank: int, port: int, out_dir: str):
+    """One of two ranks sharing the card: its own first-stage gradient first (no process group), then the same step with
+    the bucketed exchange over a 2-rank gloo group (RCCL refuses two ranks on one device; the BucketReducer, the
+    communication stream, the segmented backward graphs and the division are the code an N-GPU job runs)."""
+    import json
+    import time
+    import torch.distributed as dist
+    t0 = time.time()
+    stamps = {}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("VAMPIC_FORCE_COLLECTIVES", None)
+    torch.set_num_threads(4)                                            # two ranks share the box's host cores
+    torch.cuda.set_device(0)
+    net = _model()
+    stamps["model"] = time.time() - t0
+    net.use_graph = True
+    x = synth.synth_image(2, 64, 64, seed=8 + rank).cuda()              # a different shard per rank
+    noise = {"y": synth.uniform((2, 640, 4, 4), 301 + 10 * rank) - 0.5, "z": synth.uniform((2, 192, 1, 1), 302 + 10 * rank) - 0.5}
+    loss_local, g_local = _step(net, x, noise)
+    stamps["local_step"] = time.time() - t0
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        assert sharding.collectives_active()
+        net.grad_reducer = sharding.BucketReducer()
+        loss_x, g_x = _step(net, x, noise)
+        stamps["exchange_step"] = time.time() - t0
+        loss_x2, g_x2 = _step(net, x, noise)                            # replay of the segmented graphs
+        stamps["replayed_step"] = time.time() - t0
+        both = [torch.empty_like(g_local, device="cpu") for _ in range(2)]
+        dist.all_gather(both, g_local.cpu())
+        want = (both[0] + both[1]) / 2
+        plan = next(p for k, p in net._plans.items() if k[0] == "full_train")
+        rec = {"rank": rank, "loss_same": loss_local == loss_x == loss_x2, "equal": bool(torch.equal(g_x.cpu(), want)),
+               "replay_equal": bool(torch.equal(g_x, g_x2)), "max_abs_diff": float((g_x.cpu() - want).abs().max()),
+               "differs_from_local": bool(not torch.equal(g_x, g_local)), "buckets": len(plan.bucket_bounds),
+               "issued": len(net.grad_reducer.log), "checksum": float(want.double().sum()), "seconds": stamps}
+        stamps["checked"] = time.time() - t0
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(rec, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_gives_the_mean_of_the_ranks_gradients(tmp_path):
+    """"run one 2-rank first_train step against the single-rank gradients before claiming the exchange".  Two
+    processes on the one card, a different shard each: after the bucketed all-reduce every rank must hold exactly
+    (g_0 + g_1) / 2 of the gradients the ranks computed alone — bit for bit (sum of two fp32 numbers, halved), on both
+    ranks, replayed identically."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_two_rank_worker, args=(r, port, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(600)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
+    print("two-rank exchange, seconds since start per rank:", r0["seconds"], r1["seconds"])
+    for r in (r0, r1):
+        assert r["equal"] and r["replay_equal"] and r["loss_same"] and r["differs_from_local"], r
+        assert r["buckets"] >= 20 and r["issued"] == 2 * r["buckets"], r
+    assert r0["checksum"] == r1["checksum"]
