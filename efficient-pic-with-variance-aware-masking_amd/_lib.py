@@ -37,6 +37,7 @@ class VamSeg(C.Structure):
 
 
 VAM_MAX_WGRAD_GROUP = 16
+VAM_MAX_EW_GROUP = 8
 
 
 class VamWgrad(C.Structure):
@@ -152,6 +153,7 @@ _SIGNATURES = {
     "vam_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "vam_gauss_train": (C.c_int, [C.c_void_p, C.c_int] * 10 + [C.c_long, C.c_int, C.c_void_p]),
     "vam_train_elementwise": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "vam_train_axpy_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vam_win_attention_bwd_workspace": (C.c_size_t, [C.c_int] * 5),
     "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
                               + [C.c_int] * 7 + [C.c_void_p]),

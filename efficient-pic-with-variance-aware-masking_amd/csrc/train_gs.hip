@@ -515,6 +515,29 @@ static inline unsigned sgrid2(long n, int block) {
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// several AXPY updates of independent windows in one launch (blockIdx.y = job): what ew_kernel<EW_AXPY> computes, per job
+struct AxpyJob {
+  const float* a;
+  const float* b;
+  float* o;
+  int lda, ldb, ldo, C4;
+  long n_vec;
+  float coef;
+};
+struct AxpyGroupArgs {
+  AxpyJob j[VAM_MAX_EW_GROUP];
+};
+
+__global__ __launch_bounds__(256) void axpy_group_kernel(const AxpyGroupArgs g) {
+  const AxpyJob& J = g.j[blockIdx.y];
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < J.n_vec; v += (long)gridDim.x * 256) {
+    const long p = v / J.C4;
+    const int c = (int)(v - p * J.C4) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(J.a + p * J.lda + c), y = *reinterpret_cast<const float4*>(J.b + p * J.ldb + c);
+    *reinterpret_cast<float4*>(J.o + p * J.ldo + c) = make_float4(x.x + J.coef * y.x, x.y + J.coef * y.y, x.z + J.coef * y.z, x.w + J.coef * y.w);
+  }
+}
+
 template <int OP>
 static int launch_ew(const EwArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((ew_kernel<OP>), dim3(sgrid2(a.n_vec, 256)), dim3(256), 0, s, a);
@@ -526,6 +549,30 @@ static int launch_ew(const EwArgs& a, hipStream_t s) {
 using namespace vam;
 
 extern "C" {
+
+int vam_train_axpy_group(const vam_ew* jobs, int n, void* stream) {
+  VAM_REQUIRE(jobs && n >= 1 && n <= VAM_MAX_EW_GROUP, "vam_train_axpy_group: 1 .. %d jobs", VAM_MAX_EW_GROUP);
+  AxpyGroupArgs g;
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const vam_ew& e = jobs[i];
+    VAM_REQUIRE(e.n_pix > 0 && e.C > 0 && e.C % 4 == 0, "vam_train_axpy_group: job %d extent", i);
+    VAM_REQUIRE(e.in[0].ptr && e.in[1].ptr && e.out[0].ptr, "vam_train_axpy_group: job %d needs in0, in1, out0", i);
+    VAM_REQUIRE(e.in[0].ld % 4 == 0 && e.in[1].ld % 4 == 0 && e.out[0].ld % 4 == 0 && e.in[0].ld >= e.C && e.in[1].ld >= e.C && e.out[0].ld >= e.C,
+                "vam_train_axpy_group: job %d row pitches", i);
+    VAM_REQUIRE((((uintptr_t)e.in[0].ptr | (uintptr_t)e.in[1].ptr | (uintptr_t)e.out[0].ptr) & 15) == 0, "vam_train_axpy_group: job %d alignment", i);
+    AxpyJob& J = g.j[i];
+    J.a = e.in[0].ptr; J.b = e.in[1].ptr; J.o = const_cast<float*>(e.out[0].ptr);
+    J.lda = e.in[0].ld; J.ldb = e.in[1].ld; J.ldo = e.out[0].ld;
+    J.C4 = e.C / 4;
+    J.n_vec = e.n_pix * (e.C / 4);
+    J.coef = e.coef;
+    most = J.n_vec > most ? J.n_vec : most;
+  }
+  for (int i = n; i < VAM_MAX_EW_GROUP; ++i) g.j[i] = AxpyJob{nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, 0.f};
+  hipLaunchKernelGGL(axpy_group_kernel, dim3(sgrid2(most, 256), n), dim3(256), 0, (hipStream_t)stream, g);
+  return check_launch("axpy_group_kernel");
+}
 
 int vam_train_elementwise(int op, const vam_ew* e, void* stream) {
   VAM_REQUIRE(e && e->n_pix > 0 && e->C > 0 && e->C % 4 == 0, "vam_train_elementwise: bad arguments");

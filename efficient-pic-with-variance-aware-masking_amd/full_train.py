@@ -464,15 +464,29 @@ class FullTrainPlan:
         def acc(dst: View, src: View, coef: float = 1.0):
             bw.call(lambda: ops.ew(L.EW_AXPY, [dst, src], [dst], coef=coef), "accumulate")
 
+        def acc_many(updates: Sequence[tuple], desc: str):
+            """[(dst, src, coef)]: dst += coef * src on windows that do not overlap each other — one launch."""
+            if os.environ.get("VAMPIC_AXPY_GROUP", "1") != "1":          # A/B arm: one launch per update, as in round 3
+                for dst, src, coef in updates:
+                    acc(dst, src, coef)
+                return
+            for i in range(0, len(updates), L.VAM_MAX_EW_GROUP):
+                arr = ops.axpy_jobs(updates[i:i + L.VAM_MAX_EW_GROUP])
+                bw.keep.append(arr)
+                bw.call(lambda arr=arr: ops.axpy_group(arr), desc)
+
         def scatter(dx: View, segs: Sequence[tuple]):
             """Add the channel ranges of a first-layer input gradient into the accumulators: segs = [(accumulator view or
-            None, channels)] in concatenation order."""
-            off = 0
+            None, channels)] in concatenation order (the backward of the torch.cat in front of the stack; the accumulators
+            of one call are different tensors or different channel ranges: one launch)."""
+            off, ups = 0, []
             for dst, c in segs:
                 if dst is not None:
-                    acc(dst, dx.window(off, c))
+                    ups.append((dst, dx.window(off, c), 1.0))
                 off += c
             assert off == dx.C
+            if ups:
+                acc_many(ups, "scatter of a first-layer input gradient")
 
         def gs_base_bwd():
             g0 = grads
@@ -536,10 +550,9 @@ class FullTrainPlan:
                 for j in range(ns - 1, -1, -1):
                     rec = self.t_chain[j]
                     s_ = rec["s"]
-                    acc(sl(G_mu, j), sl(D_mutot, j))                                      # mu_total_j = mu_j + y_hat_base_j
-                    if mu_rep:
-                        acc(sl(D_yb, j), sl(D_mutot, j))
-                    acc(sl(dsg_l, j), sl(D_stdp, j))
+                    acc_many([(sl(G_mu, j), sl(D_mutot, j), 1.0)] +                      # mu_total_j = mu_j + y_hat_base_j
+                             ([(sl(D_yb, j), sl(D_mutot, j), 1.0)] if mu_rep else []) +
+                             [(sl(dsg_l, j), sl(D_stdp, j), 1.0)], "supports' gradients of slice j")
                     st = [m.cc_mean_transforms_prog[j], m.cc_scale_transforms_prog[j]]
                     dxm, dxs_ = lower_stacks_backward(bw, rec["t"], [sl(G_mu, j), sl(dsg_l, j)], [pk(s) for s in st], grads)
                     done(st[0])

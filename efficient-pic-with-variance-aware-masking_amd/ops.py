@@ -682,6 +682,25 @@ def ew(op: int, ins: Sequence[View], outs: Sequence[View], coef: float = 0.0, fl
     L.check(L.load().vam_train_elementwise(op, C.byref(e), stream_ptr()), "vam_train_elementwise")
 
 
+def axpy_jobs(updates: Sequence[tuple]):
+    """Pre-marshalled jobs of :func:`axpy_group`: updates = [(dst, src, coef)] means dst += coef * src on channel windows of
+    equal extent.  Returns the ctypes array (keep it alive as long as a plan step refers to it)."""
+    assert 1 <= len(updates) <= L.VAM_MAX_EW_GROUP
+    arr = (L.VamEw * len(updates))()
+    for e, (dst, src, coef) in zip(arr, updates):
+        assert dst.n_pix == src.n_pix and dst.C == src.C
+        e.inp[0].ptr, e.inp[0].ld = dst.ptr, dst.ld
+        e.inp[1].ptr, e.inp[1].ld = src.ptr, src.ld
+        e.out[0].ptr, e.out[0].ld = dst.ptr, dst.ld
+        e.n_pix, e.C, e.flag, e.coef = dst.n_pix, dst.C, 0, float(coef)
+    return arr
+
+
+def axpy_group(arr):
+    """Several ``dst += coef * src`` updates of windows that do not overlap, ONE launch (vam_train_axpy_group)."""
+    L.check(L.load().vam_train_axpy_group(arr, len(arr), stream_ptr()), "vam_train_axpy_group")
+
+
 def flat_view(t: torch.Tensor, width: int = 4) -> View:
     """A contiguous fp32 tensor of any shape as an [n/width, width] channel window (element-wise kernels only)."""
     assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() % width == 0

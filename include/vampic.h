@@ -408,6 +408,12 @@ typedef struct vam_ew {
   int32_t pad_;
 } vam_ew;
 int vam_train_elementwise(int op, const vam_ew* e, void* stream);
+/* n <= VAM_MAX_EW_GROUP independent VAM_EW_AXPY updates (out0 = in0 + coef * in1, each job with its own windows, extent and
+ * coefficient) in ONE launch: the backward of `torch.cat` in front of a slice stack (pic.py:407-408, 452-453: the first layer's
+ * input gradient is added, channel range by channel range, into the accumulators of the concatenated tensors).  Windows WRITTEN
+ * by different jobs of one call must not overlap. */
+#define VAM_MAX_EW_GROUP 8
+int vam_train_axpy_group(const vam_ew* jobs, int n, void* stream);
 /* Backward of vam_win_attention: dqkv [B,H,W,3C] (dq | dk | dv, same layout as qkv) from dout = dL/d(attention output),
  * and the relative-position-bias gradient WRITTEN to dtable [(2ws-1)^2][heads].  Deterministic: every (window, head group)
  * block writes its partial table into `workspace` (vam_win_attention_bwd_workspace bytes, caller-owned) and a second
