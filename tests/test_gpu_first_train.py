@@ -196,7 +196,7 @@ def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single, **variant)
         force["prog_sym"] = torch.round(nchw(pl.rq) - nchw(pl.mu_p))
         force["mask"] = nchw(pl.mask)
     # the eager and the hipGraph pass of one test take the same decisions (same kernels, same order): one oracle step serves both
-    key = (id(sd), len(sd), float(x.double().sum()), tuple(qualities), str(lmbda), single, tuple(sorted(variant.items())))
+    key = (_sd_print(sd), float(x.double().sum()), tuple(qualities), str(lmbda), single, tuple(sorted(variant.items())))
     hit = _ORACLE_CACHE.get("last")
     if hit is not None and hit[0] == key and all(torch.equal(hit[2][k], force[k]) for k in force):
         return hit[1], force
@@ -208,6 +208,12 @@ def _forced_oracle_step(sd, net, x, ny, nz, qualities, lmbda, single, **variant)
 
 
 _ORACLE_CACHE: dict = {}
+
+
+def _sd_print(sd) -> tuple:
+    """Cheap fingerprint of a state dict (tests build the same synthetic model more than once)."""
+    ks = [k for k in sorted(sd) if torch.is_tensor(sd[k]) and sd[k].dtype.is_floating_point]
+    return (len(sd),) + tuple(float(sd[k].double().sum()) for k in (ks[0], ks[len(ks) // 2], ks[-1]))
 
 
 def _decision_audit(net, sd, free, force, tol=1e-3):
@@ -303,9 +309,12 @@ def test_first_train_step_matches_reference(use_graph):
     # (z, base slices 0..9, progressive slices 0..9), the FIRST stage that differs must differ only in rounding-boundary
     # events of the oracle's own numbers (residual within 1e-3 of x.5); everything after it is conditioned on them and is
     # only counted.  A wrong kernel differs in non-boundary elements of an untainted stage.
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        free = O.training_forward(sd, x, [0, 10], ny, nz)
+    fkey = ("free", _sd_print(sd), float(x.double().sum()))
+    if _ORACLE_CACHE.get("free", (None,))[0] != fkey:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _ORACLE_CACHE["free"] = (fkey, O.training_forward(sd, x, [0, 10], ny, nz))
+    free = _ORACLE_CACHE["free"][1]
     rep = _decision_audit(net, sd, free, force)
     gold = np.load(os.path.join(GOLD, "first_train_step.npz"))
     flips = int((( _plan_of(net).y_base.torch_nchw().cpu() - torch.from_numpy(gold["y_hat_base"])).abs() > 0.4).sum())
