@@ -211,8 +211,8 @@ def test_weight_gradient_planning_is_host_arithmetic():
     """``vam_conv_wgrad_plan`` (pixel splits + workspace of a weight-gradient problem) is pure host arithmetic on the
     problem's extents: callable without a GPU, deterministic, and consistent with what the launch will need —
     workspace = splits x (N C taps + N) floats, no split for problems that already fill the chip, never more splits
-    than 256-pixel ranges.  (The tile the kernel picks — 96x64 where N is a multiple of 96 and C >= 64 — enters through
-    the number of weight tiles.)"""
+    than 256-pixel ranges.  (The tile the LDS-tiled kernel picks — csrc/wgrad_lds.hip:wgrad2_tile, e.g. 96x64 where N = 96 —
+    enters through the number of weight tiles and the makespan model of wgrad2_splits.)"""
     import ctypes
     lib = L.load()
 
