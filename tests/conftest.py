@@ -1,6 +1,15 @@
 import os
 import sys
 
+# The oracle runs on the host's OpenMP threads.  With libgomp's default ACTIVE wait policy its workers spin at every barrier;
+# on a shared / virtualised host a descheduled vCPU then stalls seven spinning ones, and the oracle tests were measured at
+# 130 - 385 s each instead of 2 - 20 s (same results).  Passive waiting degrades gracefully (measured under eight competing
+# busy loops: 39 s vs > 140 s for a 2.7 s test).  Must be set before libgomp initialises, i.e. before torch is imported.  The
+# thread COUNT is left alone: the fixtures were generated with this container's default, and oneDNN's summation order — hence a
+# boundary symbol of the demo image — depends on it.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
