@@ -56,6 +56,37 @@ def test_elementwise_derivatives_match_autograd():
     assert torch.equal(dv.torch_nchw().cpu(), v.grad)
 
 
+def test_grouped_axpy_equals_the_single_updates():
+    """vam_train_axpy_group (the backward of the torch.cat in front of a slice stack, pic.py:407-408,452-453): up to eight
+    ``dst += coef * src`` updates of channel windows with their own extents and row pitches in one launch — the same bits
+    as eight vam_train_elementwise(VAM_EW_AXPY) launches; bad argument lists are refused."""
+    B, H, W = 2, 4, 8
+    acc = [ops.new_view(B, H, W, c) for c in (320, 32, 160, 64)]
+    for k, a in enumerate(acc):
+        a.buf.copy_(synth.normal(tuple(a.buf.shape), 40 + k).cuda())
+    dx = ops.new_view(B, H, W, 320 + 32 + 96 + 64)
+    dx.buf.copy_(synth.normal(tuple(dx.buf.shape), 50).cuda())
+    ups = [(acc[0], dx.window(0, 320), 1.0), (acc[1], dx.window(320, 32), 1.0), (acc[2].window(32, 96), dx.window(352, 96), -0.5),
+           (acc[3], dx.window(448, 64), 2.0)]
+    want = [a.buf.clone() for a in acc]
+    ref = [ops.View(w, a.c0, a.C) for w, a in zip(want, acc)]
+    ref_ups = [(ref[0], ups[0][1], 1.0), (ref[1], ups[1][1], 1.0), (ref[2].window(32, 96), ups[2][1], -0.5), (ref[3], ups[3][1], 2.0)]
+    for dst, src, coef in ref_ups:
+        ops.ew(L.EW_AXPY, [dst, src], [dst], coef=coef)
+    arr = ops.axpy_jobs(ups)
+    ops.axpy_group(arr)
+    torch.cuda.synchronize()
+    for a, w in zip(acc, want):
+        assert torch.equal(a.buf, w)
+    assert not torch.equal(acc[2].buf[..., 32:128], synth.normal(tuple(acc[2].buf.shape), 42).cuda()[..., 32:128])     # it did update
+    with pytest.raises(AssertionError):
+        ops.axpy_jobs([ups[0]] * 9)                                     # more than VAM_MAX_EW_GROUP
+    bad = ops.axpy_jobs([ups[0]])
+    bad[0].C = 6                                                        # not a multiple of 4
+    with pytest.raises(L.VamError):
+        ops.axpy_group(bad)
+
+
 @pytest.mark.parametrize("dim,ws,hw", [(192, 8, (16, 24)), (320, 4, (8, 8))])
 def test_attention_block_backward(dim, ws, hw):
     """Win_noShift_Attention (residual units, Swin block with shift / mask / relative-position bias, sigmoid gate): taped
