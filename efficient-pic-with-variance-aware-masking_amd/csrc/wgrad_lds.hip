@@ -442,7 +442,7 @@ int wgrad2_splits(const vam_wgrad& p) {
   if (wg_per_cu > by_waves) wg_per_cu = by_waves;
   if (wg_per_cu < 1) wg_per_cu = 1;
   long slots = 256 * wg_per_cu;                                 // MI355X: 256 CUs
-  if (p.slot_share > 0.f && p.slot_share < 1.f) {               // the problem shares its launch with others
+  if (p.slot_share > 0.f && p.slot_share != 1.f) {              // the problem shares its launch with others (or, > 1: plans finer)
     slots = (long)(slots * (double)p.slot_share + 0.5);
     if (slots < 1) slots = 1;
   }

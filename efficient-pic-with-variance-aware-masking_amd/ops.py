@@ -624,8 +624,13 @@ def wgrad_plan(problems: Sequence[L.VamWgrad]):
     lib = L.load()
     work = [float(p.B) * p.H * p.W * p.C * p.N * p.kh * p.kw for p in problems]
     tot = sum(work) or 1.0
+    # VAMPIC_WGRAD_SHARE (experiment): the fraction of the chip a weight-gradient launch is planned against.  On a branch of
+    # its own (engine.Plan.wgrad_branch) a launch shares the chip with the data-gradient chain.
+    chip = float(os.environ.get("VAMPIC_WGRAD_SHARE", "1.0"))
     for p, w in zip(problems, work):
-        p.slot_share = 0.0 if len(problems) == 1 else max(w / tot, 1e-3)
+        share = 1.0 if len(problems) == 1 else max(w / tot, 1e-3)
+        share *= chip
+        p.slot_share = 0.0 if share == 1.0 else max(share, 1e-3)
         nbytes = C.c_size_t(0)
         p.splits = lib.vam_conv_wgrad_plan(C.byref(p), C.byref(nbytes))
         if p.splits > 1:                  # caller-owned scratch for the pixel-split partial tiles; lives with the problem
