@@ -225,6 +225,22 @@ class Plan:
     # pixel-split scratch, so the branch needs no other ordering; :meth:`join` (and the end of every :meth:`run_range`)
     # orders the main branch behind it.
     wgrad_branch: Optional[int] = None
+    wgrad_branches = 1        # > 1: consecutive weight-gradient launches alternate over this many branches (experiment)
+    _wgrad_rr = 0
+
+    def _next_wgrad_branch(self) -> int:
+        b = self.wgrad_branch + (self._wgrad_rr % max(1, self.wgrad_branches))
+        self._wgrad_rr += 1
+        return b
+
+    def join_wgrad(self):
+        """The current branch waits for every weight-gradient branch."""
+        if self.wgrad_branch is not None:
+            for k in range(max(1, self.wgrad_branches)):
+                self.join(self.wgrad_branch + k)
+
+    def _on_wgrad_branch(self) -> bool:
+        return self.wgrad_branch is not None and self.wgrad_branch <= self.cur_branch < self.wgrad_branch + max(1, self.wgrad_branches)
 
     def join(self, b: Optional[int]):
         """The current branch waits for everything recorded on branch ``b`` so far."""
@@ -244,11 +260,11 @@ class Plan:
         everything recorded so far on the current branch: for a sub-chain that ENDS in parameter gradients — a ``now``
         weight-gradient launch into a temporary plus the step that re-indexes it, a bias-gradient column sum — which nothing
         later on the current branch reads."""
-        if self.wgrad_branch is None or not self.wgrad_units or self.cur_branch == self.wgrad_branch:
+        if self.wgrad_branch is None or not self.wgrad_units or self._on_wgrad_branch():
             yield
             return
         ev, b0 = self.record(), self.cur_branch
-        self.branch(self.wgrad_branch)
+        self.branch(self._next_wgrad_branch())
         self.wait(ev)
         try:
             yield
@@ -261,9 +277,9 @@ class Plan:
         if self._wgrad_pending is not None and not now:
             self._wgrad_pending += list(problems)
             return
-        if self.wgrad_branch is not None and not now and self.cur_branch != self.wgrad_branch and problems:
+        if self.wgrad_branch is not None and not now and not self._on_wgrad_branch() and problems:
             ev, b0 = self.record(), self.cur_branch
-            self.branch(self.wgrad_branch)
+            self.branch(self._next_wgrad_branch())
             self.wait(ev)
             try:
                 self.wgrad(problems, now=True)

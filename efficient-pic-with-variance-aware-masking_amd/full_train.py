@@ -432,6 +432,7 @@ class FullTrainPlan:
         side = int(os.environ.get("VAMPIC_WGRAD_SIDE", WGRAD_SIDE_DEFAULT))
         bw.wgrad_branch = WGRAD_BRANCH if side >= 1 else None
         bw.wgrad_units = side >= 3
+        bw.wgrad_branches = int(os.environ.get("VAMPIC_WGRAD_BRANCHES", "1"))
 
         def transform_bwd(fn, *a, **kw):            # g_a / g_s: their launches fill the chip on their own
             keep_ = bw.wgrad_branch
@@ -598,7 +599,7 @@ class FullTrainPlan:
             else:
                 bw.join(GS_BASE_BRANCH)
             if shared_dec:
-                bw.join(bw.wgrad_branch)                        # both passes' weight gradients are final
+                bw.join_wgrad()                                 # both passes' weight gradients are final
                 main, tmp = self._shared_sum
                 bw.call(lambda: ops.ew(L.EW_AXPY, [ops.flat_view(main), ops.flat_view(tmp)], [ops.flat_view(main)], coef=1.0),
                         "single decoder: sum of the two passes' gradients")
