@@ -204,7 +204,7 @@ class Plan:
     _wgrad_pending: Optional[list] = None
 
     def defer_wgrad(self):
-        # OFF by default: measured SLOWER (interleaved on one box, gpurun_out/r4_defer*.log: first_train 141.9 vs 137.7 ms).
+        # OFF by default: measured SLOWER (interleaved on one box, profiles/r04_first_train_ab.txt: first_train 141.9 vs 137.7 ms).
         # A weight gradient launched right behind the data-gradient launch that produced its dY finds dY in the 256 MB
         # last-level cache; deferred to the end of the transform, both operands come from HBM.  VAMPIC_WGRAD_DEFER=1 opts in.
         if self._wgrad_pending is None and os.environ.get("VAMPIC_WGRAD_DEFER", "0") == "1":

@@ -613,7 +613,7 @@ def train_tape_planes(H: int, W: int) -> bool:
     """Policy: write the taped activations of the training slice stacks as bf16x3 planes where forward convolution and
     weight gradient can both read them.  OFF by default — built, bit-identical (tests/test_gpu_wgrad_lds.py), and measured
     no faster on the first_train step (interleaved on one box: 140.2 / 140.3 ms with, 140.1 / 139.9 without,
-    gpurun_out/r4_p3o*.log: the forward gains what the 1.5x bytes of the plane stores cost the backward).
+    profiles/r04_first_train_ab.txt: the forward gains what the 1.5x bytes of the plane stores cost the backward).
     ``VAMPIC_TRAIN_P3=1`` switches it on."""
     return os.environ.get("VAMPIC_TRAIN_P3", "0") == "1" and wgrad_reads_planes(H, W)
 
