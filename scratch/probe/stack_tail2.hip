@@ -26,12 +26,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int C_IN = 128, C_MID = 64, C_OUT = 32, HH = 16, WW = 16, TR = 4;
+#ifndef TR_ROWS
+#define TR_ROWS 4
+#endif
+constexpr int C_IN = 128, C_MID = 64, C_OUT = 32, HH = 16, WW = 16, TR = TR_ROWS;      // -DTR_ROWS=2: two output rows per workgroup (4 waves, 73 KB: two per CU)
 constexpr int HALO_W = WW + 2;                      // zero column left and right
 constexpr int IN_ROWS = TR + 4, MID_ROWS = TR + 2;  // input rows r0-2 .. r0+TR+1, layer-4 rows r0-1 .. r0+TR
 constexpr int IN_PIX = IN_ROWS * HALO_W;            // 144
 constexpr int MID_PIX = MID_ROWS * HALO_W;          // 108 (columns 0 and 17 stay zero)
-constexpr int NT = 384;
+constexpr int NPB4 = (TR + 2) / 2, NPB5 = TR / 2;  // 32-pixel blocks (two image rows) of layer 4 / layer 5
+constexpr int NT = 64 * NPB4 * 2;                  // one wave per (pixel block, 32-channel block) of layer 4
+constexpr int NIN = (IN_PIX * 12 + NT - 1) / NT, NWR = (C_MID * 12 + NT - 1) / NT;
 constexpr int S_IN = IN_PIX * 192;                  // one 32-channel chunk of the input tile: 27,648 B
 constexpr int S_MID = MID_PIX * 2 * 192;            // layer-4 output, 2 chunks: 41,472 B
 constexpr int S_SLAB = C_MID * 192;                 // 12,288 B (layer-5 slabs use the first half)
@@ -88,9 +93,9 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
 
   // ---- staging roles
   // input chunk: IN_PIX x 12 units of 16 B; unit u -> pixel u / 12, e = u % 12 = (group e / 3, plane e % 3) in the P3 source
-  auto load_in = [&](int chunk, u32x4 (&r)[5]) {
+  auto load_in = [&](int chunk, u32x4 (&r)[NIN]) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NIN; ++i) {
       const int u = tid + NT * i;
       r[i] = u32x4{0, 0, 0, 0};
       if (u < IN_PIX * 12) {
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
       }
     }
   };
-  auto store_in = [&](const u32x4 (&r)[5]) {
+  auto store_in = [&](const u32x4 (&r)[NIN]) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NIN; ++i) {
       const int u = tid + NT * i;
       if (u < IN_PIX * 12) {
         const int px = u / 12, e = u - px * 12, g = e / 3, pl = e - g * 3;
@@ -113,16 +118,16 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
     }
   };
   // weight slab: rows x 12 units of 16 B, packed row = [plane][group] already
-  auto load_w = [&](const unsigned char* w, int rows, u32x4 (&r)[2]) {
+  auto load_w = [&](const unsigned char* w, int rows, u32x4 (&r)[NWR]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NWR; ++i) {
       const int u = tid + NT * i;
       r[i] = u < rows * 12 ? *reinterpret_cast<const u32x4*>(w + (size_t)u * 16) : u32x4{0, 0, 0, 0};
     }
   };
-  auto store_w = [&](int buf, int rows, const u32x4 (&r)[2]) {
+  auto store_w = [&](int buf, int rows, const u32x4 (&r)[NWR]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NWR; ++i) {
       const int u = tid + NT * i;
       if (u < rows * 12) {
         const int row = u / 12, c = u - row * 12;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
   };
 
   // =============================================================== layer 4: 96 pixels x 64 channels, K = 4 chunks x 9 taps x 2
-  const int pb4 = wid % 3, nb4 = wid / 3;                      // pixel block (32 of the 96), channel block
+  const int pb4 = wid % NPB4, nb4 = wid / NPB4;                      // pixel block (32 of the 96), channel block
   const int p4 = pb4 * 32 + l31;                               // layer-4 pixel: row p4 / 16 of MID_ROWS, column p4 % 16
   const int my = p4 >> 4, mx = p4 & 15;
   f32x16 acc4;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
   for (int r = 0; r < 16; ++r) acc4[r] = 0.f;
   // weight slabs: slab s is requested at step s - 2 (two register sets, alternating), stored to LDS ring slot s & 1 at step
   // s, one barrier before its use: two steps of latency hidden
-  u32x4 rin[5], rwA[2], rwB[2];
+  u32x4 rin[NIN], rwA[NWR], rwB[NWR];
   auto w4_of = [&](int it_) { const int nc = it_ / 9, nt = it_ - nc * 9; return P.w4 + (size_t)(nt * 4 + nc) * C_MID * 192; };
   load_in(0, rin);
   load_w(w4_of(0), C_MID, rwA);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
     }
   }
   // =============================================================== layer 5: 64 pixels x 32 channels, K = 2 chunks x 9 taps x 2
-  const int p5 = (wid & 1) * 32 + l31;                         // waves 0 and 1 compute; the others only stage slabs
+  const int p5 = (wid % NPB5) * 32 + l31;                      // waves 0 .. NPB5-1 compute; the others only stage slabs
   const int oy = p5 >> 4, ox = p5 & 15;
   f32x16 acc5;
 #pragma unroll
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
       if (it + 2 < 18) load_w(w5_of(it + 2), C_OUT, rwA);
     }
     __syncthreads();
-    if (wid < 2) {
+    if (wid < NPB5) {
       const int ty = tap / 3, tx = tap - ty * 3;
       const int mpx = (oy + ty) * HALO_W + ox + tx;            // layer-4 halo pixel (rows r0-1.., columns with the zero border)
 #pragma unroll
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(NT) void stack_tail2_kernel(const Args a) {
       }
     }
   }
-  if (wid < 2) {
+  if (wid < NPB5) {
     float* o = P.out + ((size_t)(img * HH + r0 + oy) * WW + ox) * C_OUT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
