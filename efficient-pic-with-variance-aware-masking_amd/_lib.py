@@ -38,6 +38,7 @@ class VamSeg(C.Structure):
 
 VAM_MAX_WGRAD_GROUP = 16
 VAM_MAX_EW_GROUP = 8
+VAM_MAX_TAIL_GROUP = 8
 
 
 class VamWgrad(C.Structure):
@@ -58,6 +59,12 @@ class VamAux(C.Structure):
 class VamEw(C.Structure):
     _fields_ = [("inp", VamAux * 4), ("out", VamAux * 3), ("n_pix", C.c_long), ("C", C.c_int32), ("flag", C.c_int32),
                 ("coef", C.c_float), ("pad_", C.c_int32)]
+
+
+class VamStackTail(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w4", C.c_void_p), ("b4", C.c_void_p), ("w5", C.c_void_p), ("b5", C.c_void_p), ("out", C.c_void_p),
+                ("post", VamAux), ("post2", VamAux), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("x_groups", C.c_int32),
+                ("ld_out", C.c_int32), ("act", C.c_int32)]
 
 
 class VamConv(C.Structure):
@@ -154,6 +161,7 @@ _SIGNATURES = {
     "vam_gauss_train": (C.c_int, [C.c_void_p, C.c_int] * 10 + [C.c_long, C.c_int, C.c_void_p]),
     "vam_train_elementwise": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "vam_train_axpy_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "vam_stack_tail_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vam_win_attention_bwd_workspace": (C.c_size_t, [C.c_int] * 5),
     "vam_win_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
                               + [C.c_int] * 7 + [C.c_void_p]),

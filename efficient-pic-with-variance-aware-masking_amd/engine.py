@@ -180,6 +180,20 @@ class Plan:
             self.class_of.append(self.cur_class)
             self.steps.append(lambda arr=arr, n=n: L.check(lib.vam_conv_group(arr, n, ops.stream_ptr()), "vam_conv_group"))
 
+    def stack_tail(self, problems: Sequence["L.VamStackTail"]):
+        """The last two layers of K slice stacks as one launch per VAM_MAX_TAIL_GROUP stacks (csrc/stack_tail.hip)."""
+        lib = L.load()
+        arr = (L.VamStackTail * len(problems))(*problems)
+        n = len(problems)
+        self.keep += [arr] + [p._keep for p in problems]
+        c0 = problems[0]
+        fl = 2.0 * n * c0.B * c0.H * c0.W * 9.0 * (128 * 64 + 64 * 32)
+        self.flops += fl
+        self.meta.append({"kind": "conv", "flops": fl, "desc": f"{n}x[128->64->32 k3x3 fused tail P={c0.B * c0.H * c0.W}]"})
+        self.branch_of.append(self.cur_branch)
+        self.class_of.append(self.cur_class)
+        self.steps.append(lambda: L.check(lib.vam_stack_tail_group(arr, n, ops.stream_ptr()), "vam_stack_tail_group"))
+
     def resunit(self, problems: Sequence["L.VamResunit"]):
         """Fused residual units (one launch per group of up to VAM_MAX_GROUP units, csrc/resunit.hip)."""
         lib = L.load()
@@ -495,6 +509,21 @@ def lower_stacks(plan: Plan, stacks: Sequence[nn.Sequential], inputs: Sequence[S
     for d in range(depth):
         probs = []
         nxt = []
+        if d == depth - 2 and depth >= 3 and plan._amax_pool is None and not plan.act16 and all(len(c) == 1 for c in cur):
+            # the last two layers as one launch (csrc/stack_tail.hip) where every stack of the group qualifies
+            fkw = [dict(final[k]) if (final is not None and final[k]) else {} for k in range(K)]
+            if all(lay[k][d][1] == L.ACT_GELU and
+                   ops.stack_tail_ok(cur[k][0], lay[k][d][0], lay[k][d + 1][0], outs[k],
+                                     dict(fkw[k], act=fkw[k].get("act", lay[k][d + 1][1]))) for k in range(K)):
+                tails = []
+                for k in range(K):
+                    x = cur[k][0]
+                    o = outs[k] if outs[k] is not None else plan.buf(x.B, x.H, x.W, 32)
+                    tails.append(ops.stack_tail_problem(x, lay[k][d][0].packed(), lay[k][d + 1][0].packed(), o,
+                                                        fkw[k].get("act", lay[k][d + 1][1]), fkw[k].get("post"), fkw[k].get("post2")))
+                    res.append(o)
+                plan.stack_tail(tails)
+                return res
         for k in range(K):
             m, act = lay[k][d]
             hd = heads.get(id(stacks[k])) if (heads is not None and d == 0) else None

@@ -687,6 +687,40 @@ def ew(op: int, ins: Sequence[View], outs: Sequence[View], coef: float = 0.0, fl
     L.check(L.load().vam_train_elementwise(op, C.byref(e), stream_ptr()), "vam_train_elementwise")
 
 
+def stack_tail_ok(x, m4, m5, out: Optional[View], kw: dict) -> bool:
+    """``out`` None = a fresh buffer.  Can the last two layers (m4: 128 -> 64 + GELU, m5: 64 -> 32) of a slice stack run as ONE launch (csrc/stack_tail.hip)?"""
+    if os.environ.get("VAMPIC_STACK_TAIL", "1") != "1" or not split_mode():
+        return False
+    if not (isinstance(x, View3) and x.C == 128 and x.g0 == 0 and x.ld == 16 and x.W == 16 and x.H % 4 == 0):
+        return False
+    if (out is not None and (type(out) is not View or out.C != 32)) or any(kw.get(k) is not None for k in ("pre", "mul")) or kw.get("flags"):
+        return False
+    if kw.get("act", L.ACT_NONE) not in (L.ACT_NONE, L.ACT_HALF_TANH) or any(v is not None and type(v) is not View for v in (kw.get("post"), kw.get("post2"))):
+        return False
+    ok = lambda m, ci, co: (type(m).__name__ == "Conv2d" and m.in_channels == ci and m.out_channels == co and m.kernel_size == 3 and m.stride == 1)
+    return ok(m4, 128, 64) and ok(m5, 64, 32)
+
+
+def stack_tail_problem(x: "View3", pk4: Packed, pk5: Packed, out: View, act: int = L.ACT_NONE, post: Optional[View] = None,
+                       post2: Optional[View] = None) -> "L.VamStackTail":
+    t = L.VamStackTail()
+    assert pk4.b is not None and pk5.b is not None and not pk4.w16 and not pk5.w16
+    t.x, t.w4, t.b4, t.w5, t.b5, t.out = x.ptr, pk4.w.data_ptr(), pk4.b.data_ptr(), pk5.w.data_ptr(), pk5.b.data_ptr(), out.ptr
+    t.B, t.H, t.W, t.x_groups, t.ld_out, t.act = x.B, x.H, x.W, x.ld, out.ld, int(act)
+    for name, v in (("post", post), ("post2", post2)):
+        if v is not None:
+            assert v.n_pix == out.n_pix and v.C == out.C
+            a = getattr(t, name)
+            a.ptr, a.ld = v.ptr, v.ld
+    t._keep = (x, pk4, pk5, out, post, post2)
+    return t
+
+
+def stack_tail_group(problems: Sequence["L.VamStackTail"]):
+    arr = (L.VamStackTail * len(problems))(*problems)
+    L.check(L.load().vam_stack_tail_group(arr, len(problems), stream_ptr()), "vam_stack_tail_group")
+
+
 def axpy_jobs(updates: Sequence[tuple]):
     """Pre-marshalled jobs of :func:`axpy_group`: updates = [(dst, src, coef)] means dst += coef * src on channel windows of
     equal extent.  Returns the ctypes array (keep it alive as long as a plan step refers to it)."""

@@ -407,6 +407,28 @@ typedef struct vam_ew {
   float coef;
   int32_t pad_;
 } vam_ew;
+/* The last two layers of a slice stack — conv3x3(128 -> 64) + GELU, conv3x3(64 -> 32) with the epilogue
+ * out = post2 + post + act(conv + bias), act = VAM_ACT_NONE or VAM_ACT_HALF_TANH — as ONE launch per VAM_MAX_TAIL_GROUP stacks
+ * (reference: the tails of the Sequentials cc_mean_transforms[_prog] / cc_scale_transforms[_prog] / lrp_transforms[_prog],
+ * models/pic.py:86-121, 550, 635-641).  x = the 128-channel input as bf16x3 planes (what a conv launch with VAM_CONV_OUT_BF3
+ * writes; x_groups = 8-channel groups per pixel of that buffer: 16, the tensor is not a window of a wider one), w4 / b4 / w5 / b5 = the packed weights and bias of the two layers
+ * as vam_conv takes them; out fp32 NHWC with row pitch ld_out.  Same bits as the two vam_conv_group launches.  Built for latents
+ * 16 columns wide (W == 16, H a multiple of 4): the caller falls back to vam_conv_group otherwise. */
+#define VAM_MAX_TAIL_GROUP 8
+typedef struct vam_stack_tail {
+  const void* x;
+  const void* w4;
+  const float* b4;
+  const void* w5;
+  const float* b5;
+  float* out;
+  vam_aux post, post2;
+  int32_t B, H, W;
+  int32_t x_groups;
+  int32_t ld_out;
+  int32_t act;
+} vam_stack_tail;
+int vam_stack_tail_group(const vam_stack_tail* probs, int n, void* stream);
 int vam_train_elementwise(int op, const vam_ew* e, void* stream);
 /* n <= VAM_MAX_EW_GROUP independent VAM_EW_AXPY updates (out0 = in0 + coef * in1, each job with its own windows, extent and
  * coefficient) in ONE launch: the backward of `torch.cat` in front of a slice stack (pic.py:407-408, 452-453: the first layer's

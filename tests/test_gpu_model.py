@@ -206,3 +206,28 @@ def test_large_batches_run_as_sub_batches(gpu_model, monkeypatch):
     # the per-image rate sums are double-precision atomics: same terms, order not fixed
     a, b = whole["log2_likelihood_sum"], parts["log2_likelihood_sum"]
     assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())
+
+
+def test_fused_stack_tail_leaves_every_output_bit_unchanged(gpu_model, monkeypatch):
+    """The slice stacks' last two layers run as one launch (csrc/stack_tail.hip) where the latent is 16 columns wide — the
+    bench configuration's 256 x 256 images; VAMPIC_STACK_TAIL=0 keeps the two conv launches.  Same plan otherwise: every
+    output of forward_single_quality (and so every symbol of the bitstream) must be identical bit for bit, and the fused
+    launches must really be in the plan."""
+    net, _ = gpu_model
+    if not vampic.ops.split_mode():
+        pytest.skip("the fused tail reads bf16x3 planes")
+    x = vampic.synth.synth_image(2, 256, 256, seed=21).cuda()
+    outs, fused = [], []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VAMPIC_STACK_TAIL", flag)
+        net._drop_plans()                                   # the switch is read when a plan is lowered
+        with torch.no_grad():
+            outs.append(net.forward_single_quality(x, 2.5))
+        plan = next(iter(net._plans.values())).plan
+        fused.append(sum("fused tail" in m["desc"] for m in plan.meta))
+    net._drop_plans()
+    assert fused[0] == 0 and fused[1] >= 20, fused          # one step per grouped launch: 16 mean+scale chains, 7 LRP groups
+    a, b = outs
+    for k in ("x_hat", "y_hat", "mask"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["likelihoods"]["y"], b["likelihoods"]["y"]) and torch.equal(a["likelihoods"]["z"], b["likelihoods"]["z"])

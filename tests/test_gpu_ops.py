@@ -402,6 +402,51 @@ def test_bf16x3_plane_tensors_are_transparent():
         ops.conv_problem(m2.packed(), [mid3.window(0, 88), mid32.window(88, 88)], o3)
 
 
+@pytest.mark.parametrize("H,K", [(16, 2), (16, 10), (4, 1), (32, 3)])
+def test_fused_stack_tail_is_bit_identical(H, K):
+    """csrc/stack_tail.hip: the last two layers of a slice stack (conv3x3 128 -> 64 + GELU, conv3x3 64 -> 32 with the stack's
+    final epilogue) in ONE launch, the 64-channel intermediate kept in LDS as bf16x3 planes — against the two conv_igemm
+    launches (planes between them) it replaces: the same bits, for plain outputs (mean / scale stacks, written into channel
+    windows of wider tensors) and for the LRP tail (0.5 tanh + quantised residual + base slice); groups larger than one
+    launch's eight stacks; what it is not built for is refused."""
+    if not ops.split_mode():
+        pytest.skip("the fused tail reads bf16x3 planes")
+    B, W = 3, 16
+    outs_a, outs_b = ops.new_view(B, H, W, 32 * K), ops.new_view(B, H, W, 32 * K)
+    post, post2 = ops.from_nchw(_rand((B, 32 * K, H, W), 70).cuda()), ops.from_nchw(_rand((B, 32 * K, H, W), 71).cuda())
+    two, fused = [[], []], []
+    keep = []
+    for k in range(K):
+        m3, m4, m5 = Ly.Conv2d(32, 128, 3, 1).cuda(), Ly.Conv2d(128, 64, 3, 1).cuda(), Ly.Conv2d(64, 32, 3, 1).cuda()
+        _fill(m3, 50 + 3 * k), _fill(m4, 51 + 3 * k), _fill(m5, 52 + 3 * k)
+        x = ops.from_nchw(_rand((B, 32, H, W), 60 + k).cuda())
+        x3 = ops.new_view3(B, H, W, 128)
+        ops.conv_group([ops.conv_problem(m3.packed(), [x], x3, L.ACT_GELU)])            # the stack's third layer writes planes
+        mid = ops.new_view3(B, H, W, 64)
+        lrp = k % 2 == 1
+        kw = dict(act=L.ACT_HALF_TANH, post=post.window(32 * k, 32), post2=post2.window(32 * k, 32) if k % 4 == 1 else None) if lrp else {}
+        two[0].append(ops.conv_problem(m4.packed(), [x3], mid, L.ACT_GELU))
+        two[1].append(ops.conv_problem(m5.packed(), [mid], outs_a.window(32 * k, 32), kw.get("act", L.ACT_NONE), post=kw.get("post"), post2=kw.get("post2")))
+        assert ops.stack_tail_ok(x3, m4, m5, outs_b.window(32 * k, 32), kw)
+        fused.append(ops.stack_tail_problem(x3, m4.packed(), m5.packed(), outs_b.window(32 * k, 32), kw.get("act", L.ACT_NONE), kw.get("post"), kw.get("post2")))
+        keep += [m3, m4, m5, x, x3, mid]
+    ops.conv_group(two[0])
+    ops.conv_group(two[1])
+    ops.stack_tail_group(fused)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs_a.buf).all() and float(outs_a.buf.abs().max()) > 1e-3
+    assert torch.equal(outs_a.buf, outs_b.buf)
+    # refused: another width, a window of a wider plane tensor, an epilogue operand it does not have
+    wide = ops.new_view3(B, H, 32, 128)
+    assert not ops.stack_tail_ok(wide, m4, m5, None, {})
+    assert not ops.stack_tail_ok(ops.new_view3(B, H, W, 256).window(128, 128), m4, m5, None, {})
+    assert not ops.stack_tail_ok(x3, m4, m5, None, {"pre": post.window(0, 32)})
+    bad = ops.stack_tail_problem(x3, m4.packed(), m5.packed(), outs_b.window(0, 32))
+    bad.W = 32
+    with pytest.raises(L.VamError):
+        ops.stack_tail_group([bad])
+
+
 def test_entropy_bottleneck_aux_loss_and_gradient():
     """model.aux_loss() (models/base.py:22-29 -> EntropyBottleneck.loss, entropy_models.py:398-401): value and the
     gradient w.r.t. the quantiles from vam_eb_aux_loss against the REFERENCE's autograd (tests/golden/entropy_ops.npz),
