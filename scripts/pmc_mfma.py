@@ -48,7 +48,7 @@ def main():
         # MODE template argument (6th) of conv_igemm_kernel: 1 = bf16 split operands (1024 FLOP/clk/SIMD, 6 MFMA FLOP per
         # algorithmic FLOP), 0 = fp32 operands (64 FLOP/clk/SIMD)
         targs = k[k.find("<") + 1:k.rfind(">")].split(",") if "<" in k else []
-        split = ("conv_igemm_kernel" in k and len(targs) >= 6 and targs[5].strip() == "1") or "resunit192_kernel" in k
+        split = ("conv_igemm_kernel" in k and len(targs) >= 6 and targs[5].strip() == "1") or "resunit192_kernel" in k or "stack_tail_kernel" in k
         tf = util * 1024 * (1024 if split else 64) * clk / 1e3
         tf_eq = tf / 6.0 if split else tf
         ldsr = a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"] if a.get("SQ_LDS_IDX_ACTIVE") else float("nan")

@@ -31,7 +31,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
     # the convolution family = the implicit-GEMM kernel and the fused residual-unit kernel (three convolutions per launch)
-    fam = {"conv_igemm": ("conv_igemm_kernel", "resunit192_kernel"), "win_attn": ("win_attn_kernel", "win_attn8_mfma_kernel"),
+    fam = {"conv_igemm": ("conv_igemm_kernel", "resunit192_kernel", "stack_tail_kernel"), "win_attn": ("win_attn_kernel", "win_attn8_mfma_kernel"),
            "variance_mask": ("variance_mask_kernel",), "gauss_tail": ("gauss_tail_kernel",)}
     res = {}
     for name, pats in fam.items():

@@ -40,7 +40,7 @@ def main():
                 cur_e = max(cur_e, e)
         union += cur_e - cur_s
         wall = max(e for _, e in iv) - iv[0][0]
-        conv = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks if "conv_igemm_kernel" in r["Kernel_Name"] or "resunit192_kernel" in r["Kernel_Name"])
+        conv = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks if "conv_igemm_kernel" in r["Kernel_Name"] or "resunit192_kernel" in r["Kernel_Name"] or "stack_tail_kernel" in r["Kernel_Name"])
         queues = {}
         for r in ks:
             q = r["Queue_Id"]
