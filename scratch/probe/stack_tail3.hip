@@ -74,7 +74,19 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2& h, uint2& m, 
 
 // LDS row of 192 B = [plane 3][4 groups x 16 B], the 16-byte unit of group g stored at g ^ ((row >> 1) & 3): the 32 lanes of a
 // half-wave read rows r .. r+15 (one image row) of one group — distinct banks for 8 consecutive rows x 2 halves
-__device__ __forceinline__ int unit_off(int row, int plane, int g) { return row * 192 + plane * 64 + ((g ^ ((row >> 1) & 3)) << 4); }
+#ifndef SWZ
+#define SWZ 0
+#endif
+__device__ __forceinline__ int swz_of(int row) {
+#if SWZ == 0
+  return (row >> 1) & 3;                          // conflict-free for 8 consecutive rows per 128 B
+#elif SWZ == 1
+  return (row >> 2) & 3;                          // conflict-free for 16 consecutive rows per 256 B
+#else
+  return ((row >> 1) & 3) ^ ((row >> 3) & 1);
+#endif
+}
+__device__ __forceinline__ int unit_off(int row, int plane, int g) { return row * 192 + plane * 64 + ((g ^ swz_of(row)) << 4); }
 
 __global__ __launch_bounds__(NT) void stack_tail3_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
